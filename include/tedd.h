@@ -1,0 +1,159 @@
+/* tedd.h -- C ABI of libtedd_hip.so: the MI355X (gfx950) implementation of the time-stepping hot
+ * path of phao/NA-nonlinear-temperature-enhanced-diffusion-model-DD.
+ *
+ * The reference has no FFI; its boundary for this path is the Python class contract
+ *   integrator_cls(semi_discrete_field=field, **params).step(at_t0: StateVars, *, t0, dt) -> StateVars
+ * (reference src/prob1base.py:2879-2882, 3117-3149; instantiated at src/mms_trial_utils.py:247-249).
+ * The host-side Python classes that keep that contract call the entry points below through ctypes.
+ * Every comment "replaces" cites the reference code (file:line under src/) whose work the entry
+ * point performs on the GPU.
+ *
+ * Conventions
+ *  - All arrays are IEEE binary64.  Host arrays are dense C-order (rows x (M+1)); index i (x, slow
+ *    axis) by j (y, fast axis), as reference src/prob1base.py:243-248,353.
+ *  - A context owns one slab of rows [row_lo, row_hi) of the (N+1) x (M+1) mesh plus `ghost` rows
+ *    on each side that is not a physical boundary; host arrays passed to/from a context cover
+ *    its local rows (ghost rows included), i.e. tedd_local_rows() x (M+1).
+ *  - All calls return 0 on success or a negative tedd_status; tedd_last_error() describes it.
+ *  - Calls on one context are not thread-safe.  Work is enqueued on the context's HIP stream;
+ *    calls that return host data synchronise that stream.
+ */
+#ifndef TEDD_H
+#define TEDD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tedd_ctx tedd_ctx;
+
+enum tedd_status {
+    TEDD_OK = 0,
+    TEDD_ERR_INVALID = -1,     /* bad argument (maps to ValueError) */
+    TEDD_ERR_ASSERT = -2,      /* a precondition the reference asserts (dt > 0, shapes): AssertionError */
+    TEDD_ERR_RUNTIME = -3,     /* HIP failure, out of memory, unsupported configuration: RuntimeError */
+    TEDD_ERR_NOT_CONVERGED = -4 /* a Jacobi solve missed its tolerance within jacobi_max sweeps */
+};
+
+enum tedd_mms_case {
+    TEDD_MMS_STREAM = -1, /* forcing arrays are uploaded with tedd_set_forcing */
+    TEDD_MMS_POL = 0,     /* src/prob1_mms_cases.py:250-277 */
+    TEDD_MMS_EXPSIN = 1,  /* src/prob1_mms_cases.py:280-337 */
+    TEDD_MMS_PEAKS = 2,   /* src/prob1_mms_cases.py:151-247; params [leading_spatial_const, evol_speed] */
+    TEDD_MMS_NFS = 3      /* src/prob1_mms_cases.py:406-511; params [gamma_cp,gamma_T,gamma_cl,gamma_cd,gamma_cs,theta] */
+};
+
+enum tedd_reaction {
+    TEDD_REACT_CSTRIPLE = 0,    /* src/prob1base.py:2842-2876 */
+    TEDD_REACT_REGHCSTRIPLE = 1 /* src/prob1base.py:3553-3593 */
+};
+
+typedef struct tedd_config {
+    int32_t N, M;             /* mesh has (N+1) x (M+1) nodes */
+    int32_t row_lo, row_hi;   /* owned global rows [row_lo, row_hi); 0 and N+1 on a single device */
+    int32_t ghost;            /* ghost rows kept on each non-physical side (0 on a single device) */
+    int32_t model_kind;       /* 1 = DefaultModel01, 2 = DefaultModel02 (src/prob1base.py:71-217) */
+    int32_t reaction_kind;    /* tedd_reaction */
+    int32_t mms_case;         /* tedd_mms_case */
+    int32_t device;           /* HIP device ordinal; -1 = current device */
+    int32_t reserved;
+    double eta;               /* regularization_factor of H_eta */
+    double consts[17];        /* ModelConsts in the reference's field order (src/prob1base.py:28-45) */
+    double mms_params[8];
+} tedd_config;
+
+/* Create a context for the grid x[0..N], y[0..M] (any strictly increasing coordinates; replaces
+ * Grid(x, y), src/prob1base.py:220-362, FiveDiagonalsMatrixFactory :601-619 and the lambdified MMS
+ * set-up :1226-1347). */
+int tedd_create(tedd_ctx** out, const tedd_config* cfg, const double* x, const double* y);
+void tedd_destroy(tedd_ctx* ctx);
+const char* tedd_last_error(const tedd_ctx* ctx); /* ctx may be NULL: error of the last failed tedd_create */
+
+/* Re-read the model constants, eta and MMS parameters (the reference's tests mutate the model in
+ * place between steps, e.g. tests/test_time_integrator_hcs_triple.py:377-387). */
+int tedd_set_model(tedd_ctx* ctx, const double consts[17], int32_t model_kind, double eta,
+                   const double mms_params[8]);
+/* Use the caller's HIP stream (hipStream_t passed as void*) for all subsequent work. */
+int tedd_set_stream(tedd_ctx* ctx, void* hip_stream);
+int tedd_sync(tedd_ctx* ctx);
+int32_t tedd_local_rows(const tedd_ctx* ctx);
+int32_t tedd_row_offset(const tedd_ctx* ctx); /* global index of local row 0 */
+int32_t tedd_pitch(const tedd_ctx* ctx);      /* device row pitch in doubles (>= M+1) */
+
+/* State (cp, T, cl, cd, cs): replaces StateVars' five arrays (src/prob1base.py:1959-2028). */
+int tedd_set_state(tedd_ctx* ctx, const double* cp, const double* T, const double* cl, const double* cd,
+                   const double* cs);
+int tedd_get_state(tedd_ctx* ctx, double* cp, double* T, double* cl, double* cd, double* cs);
+/* Device addresses of the current state arrays (pitched, local rows); for halo exchange. */
+int tedd_state_device_ptrs(tedd_ctx* ctx, void* ptrs[5]);
+/* Tell the context that the caller refreshed the ghost rows of the current state arrays (after a
+ * halo exchange written through tedd_state_device_ptrs). */
+int tedd_ghosts_refreshed(tedd_ctx* ctx);
+/* Load the state with the exact MMS solution at time t (state_from_mms_when, src/prob1base.py:3433-3449). */
+int tedd_set_state_exact(tedd_ctx* ctx, double t);
+
+/* Forcing arrays for TEDD_MMS_STREAM at the two time levels of the next step (which: 0 = t0,
+ * 1 = t0+dt): cell-averaged fcp, fT, fcl, fcd, fcs (src/prob1base.py:2313-2425, 3468-3551). */
+int tedd_set_forcing(tedd_ctx* ctx, int32_t which, const double* fcp, const double* fT, const double* fcl,
+                     const double* fcd, const double* fcs);
+
+/* One predictor-corrector step of P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_{RegHCsTriple,CsTriple}
+ * (src/prob1base.py:3117-3149 with 2953-3115, 3174-3219, 3631-3702).  The 5-diagonal systems the
+ * reference solves with spsolve (src/prob1base.py:2103,2130) are solved by matrix-free Jacobi
+ * sweeps: jacobi_sweeps[v] > 0 fixes the sweep count for v = T, cl, cd; <= 0 picks it from the
+ * contraction bound of the system so that the last update is below jacobi_tol relative to the
+ * solution increment (capped at jacobi_max).  jacobi_sweeps may be NULL (all automatic). */
+int tedd_step_pc(tedd_ctx* ctx, double t0, double dt, int32_t num_pc_steps, int32_t num_newton_steps,
+                 int32_t cs_newton_iterations, double cs_consec_xs_rtol, const int32_t jacobi_sweeps[3],
+                 double jacobi_tol, int32_t jacobi_max);
+/* ForwardEulerIntegrator.step (src/prob1base.py:2885-2903). */
+int tedd_step_feuler(tedd_ctx* ctx, double t0, double dt);
+
+/* nsteps steps from t0 with the error norms of run_simulation_collect_data fused in
+ * (src/mms_trial_utils.py:56-147): err_series receives (nsteps+1) x 8 doubles, per time level
+ * ||e_v||_H^2 for v = cp,T,cl,cd,cs then ||grad_H e_v||_p^2 for v = T,cl,cd (owned rows only).
+ * integrator: 0 = forward Euler, 1 = predictor-corrector.  err_series may be NULL. */
+int tedd_advance(tedd_ctx* ctx, double t0, double dt, int32_t nsteps, int32_t integrator, int32_t num_pc_steps,
+                 int32_t num_newton_steps, int32_t cs_newton_iterations, double cs_consec_xs_rtol,
+                 const int32_t jacobi_sweeps[3], double jacobi_tol, int32_t jacobi_max, double* err_series);
+
+/* last_residual["T"|"cl"|"cd"] of the last predictor-corrector step (src/prob1base.py:3041-3043,
+ * 3076-3078, 3111-3113); computed on demand. */
+int tedd_get_residuals(tedd_ctx* ctx, double* rT, double* rcl, double* rcd);
+
+/* Parity hooks.  F(state, t): Fcp, FT, Fcl, Fcd, Fcs (src/prob1base.py:2599-2672). */
+int tedd_eval_field(tedd_ctx* ctx, double t, double* Fcp, double* FT, double* Fcl, double* Fcd, double* Fcs);
+/* Exact MMS solution at the nodes (closed-form cases). */
+int tedd_eval_exact(tedd_ctx* ctx, double t, double* cp, double* T, double* cl, double* cd, double* cs);
+/* The five forcing arrays at time t (closed-form cases). */
+int tedd_eval_forcing(tedd_ctx* ctx, double t, double* fcp, double* fT, double* fcl, double* fcd, double* fcs);
+/* Jacobian stencil coefficients at the current state: op 0 dFT/dT, 1 dFcl/dT, 2 dFcl/dcl, 3 dFcd/dT,
+ * 4 dFcd/dcl, 5 dFcd/dcd (src/prob1base.py:2674-2839); out arrays: (0,0),(+1,0),(-1,0),(0,+1),(0,-1). */
+int tedd_eval_jacobian(tedd_ctx* ctx, int32_t op, double* c, double* e, double* w, double* n, double* s);
+/* Error norms of the current state against the exact solution at t: 8 doubles as in tedd_advance
+ * (src/mms_trial_utils.py:81-110).  For TEDD_MMS_STREAM pass the exact fields in exact[5]. */
+int tedd_error_norms(tedd_ctx* ctx, double t, const double* const exact[5], double out[8]);
+
+/* Record of the last step: sweeps[3] Jacobi sweeps used for T, cl, cd; last_update[3] and
+ * increment[3]: max-norms of the last sweep's update and of the solution increment;
+ * cs_iterations: Newton iterations the cs corrector kept (global early exit, src/prob1base.py:3661). */
+typedef struct tedd_step_stats {
+    int32_t sweeps[3];
+    int32_t cs_iterations;
+    double last_update[3];
+    double increment[3];
+} tedd_step_stats;
+int tedd_get_stats(tedd_ctx* ctx, tedd_step_stats* out);
+
+/* Per-kernel device timing with HIP events on the context's stream.  enable != 0 starts
+ * recording (and clears the totals).  tedd_profile_get returns, for up to `cap` kernel families,
+ * the name, the number of launches and the summed milliseconds; returns the number of families. */
+int tedd_profile_enable(tedd_ctx* ctx, int32_t enable);
+int tedd_profile_get(tedd_ctx* ctx, int32_t cap, const char** names, int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEDD_H */

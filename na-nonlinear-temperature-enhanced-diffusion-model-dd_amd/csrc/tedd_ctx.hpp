@@ -1,0 +1,870 @@
+// Context of one slab: geometry tables, device buffers, and the sequencing of one
+// predictor-corrector / forward-Euler step over the node functors of tedd_nodes.hpp.
+// The class is a template over the execution backend: the shipped library instantiates it
+// with the HIP backend (tedd_hip_backend.hpp); tests/cpu_twin instantiates it with a host
+// loop backend to debug the sequencing without a GPU.
+//
+// Reference sequencing: src/prob1base.py:3117-3149 (step), 2998-3115 (Newton steps),
+// 2885-2903 (forward Euler); src/mms_trial_utils.py:56-147 (advance with error norms).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tedd.h"
+#include "tedd_mms_host.hpp"
+#include "tedd_nodes.hpp"
+
+namespace tedd {
+
+struct AssertError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct InvalidError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct NotConverged : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// kernel families for the timing record
+enum Fam : int {
+    FAM_PREDICT = 0, FAM_RHS_T, FAM_RHS_CL, FAM_RHS_CD, FAM_JACOBI_T, FAM_JACOBI_CL, FAM_JACOBI_CD,
+    FAM_CORRECT, FAM_CS_NEWTON, FAM_FIELD, FAM_RESIDUAL, FAM_NORMS, FAM_MISC, FAM_SOLVE_T, FAM_SOLVE_CL,
+    FAM_SOLVE_CD, FAM_COUNT
+};
+inline const char* fam_name(int f) {
+    static const char* n[FAM_COUNT] = {"predict", "rhs_T", "rhs_cl", "rhs_cd", "jacobi_T", "jacobi_cl",
+                                       "jacobi_cd", "correct", "cs_newton", "field", "residual", "norms",
+                                       "misc", "solve_T", "solve_cl", "solve_cd"};
+    return n[f];
+}
+
+struct Range {
+    int lo, hi;
+};
+
+template <class Backend>
+class Ctx {
+public:
+    Backend be;
+    tedd_config cfg;
+    int N, M, nrows, ncols, ld, i0, gl, gr;
+    std::vector<double> xg, yg;  // global coordinates
+    ModelC model;
+    MmsParams mp;
+    int mms_case, react;
+    std::string last_error;
+
+    // device geometry + MMS tables
+    double* d_geo_rows = nullptr;  // rh, rhm, hm, h : 4 x nrows
+    double* d_geo_cols = nullptr;  // rk, rkm, km, k : 4 x ld
+    double *d_bx = nullptr, *d_by = nullptr, *d_bxq = nullptr, *d_byq = nullptr;
+    double q_metric = 0.0;  // max over the mesh of Cx- + Cx+ + Cy- + Cy+
+
+    // field buffers: a pool of (nrows x ld) arrays.  Named slots are dedicated; state and
+    // intermediate unknowns are acquired from / released to the free list.
+    enum Slot : int { Y0 = 0, RHS = 3, DA, DB, FCPA, FCPB, SF00 /*5*/, SF10 = 13 /*5*/, EX0 = 18 /*5*/, NSLOT = 23 };
+    double* slot[NSLOT] = {nullptr};
+    std::vector<double*> all_bufs, free_bufs;
+    std::vector<double*> retained;  // kept alive after a step for tedd_get_residuals
+    double* cur[5];
+    std::map<const double*, Range> valid;
+
+    // small device scratch: reductions and records
+    double* d_red = nullptr;      // 64 doubles
+    double* d_series = nullptr;   // error-norm series of tedd_advance
+    size_t series_cap = 0;
+    int* d_ints = nullptr;        // [0] cs iterations kept
+
+    // record of the last PC step (for residuals and stats)
+    struct LastStep {
+        bool have = false;
+        double t1 = 0, dt = 0;
+        const double *cp_used = nullptr, *cs_used = nullptr;
+        int sweeps[3] = {0, 0, 0};
+        int cs_iters_requested = 0;
+        bool cs_newton_ran = false;
+    } last;
+    bool stats_pending = false;
+
+    // cp-forcing cell-average cache: fcp_buf[k] holds the array at time fcp_time[k]
+    double fcp_time[2] = {NAN, NAN};
+    bool stream_forcing_set[2] = {false, false};
+
+    Ctx(const tedd_config& c, const double* x, const double* y) : cfg(c) {
+        N = c.N;
+        M = c.M;
+        if (N < 2 || M < 2) throw InvalidError("mesh needs N >= 2 and M >= 2");
+        if (c.row_lo < 0 || c.row_hi > N + 1 || c.row_lo >= c.row_hi) throw InvalidError("bad row range");
+        if (c.ghost < 0) throw InvalidError("ghost < 0");
+        if (c.model_kind != 1 && c.model_kind != 2) throw InvalidError("model_kind must be 1 or 2");
+        if (c.reaction_kind != REACT_CS3 && c.reaction_kind != REACT_REG) throw InvalidError("bad reaction_kind");
+        if (c.mms_case < CASE_STREAM || c.mms_case > CASE_NFS) throw InvalidError("bad mms_case");
+        xg.assign(x, x + N + 1);
+        yg.assign(y, y + M + 1);
+        for (int i = 1; i <= N; ++i)
+            if (!(xg[i] > xg[i - 1])) throw InvalidError("x must be strictly increasing");
+        for (int j = 1; j <= M; ++j)
+            if (!(yg[j] > yg[j - 1])) throw InvalidError("y must be strictly increasing");
+        gl = (c.row_lo > 0) ? std::min(c.ghost, c.row_lo) : 0;
+        gr = (c.row_hi < N + 1) ? std::min(c.ghost, N + 1 - c.row_hi) : 0;
+        if ((c.row_lo > 0 || c.row_hi < N + 1) && c.ghost < 1) throw InvalidError("a partial slab needs ghost >= 1");
+        i0 = c.row_lo - gl;
+        nrows = (c.row_hi - c.row_lo) + gl + gr;
+        ncols = M + 1;
+        ld = ((ncols + 15) / 16) * 16;
+        mms_case = c.mms_case;
+        react = c.reaction_kind;
+        be.init(c.device);
+        set_model(c.consts, c.model_kind, c.eta, c.mms_params);
+        build_geometry();
+        build_mms_tables();
+        d_red = (double*)be.alloc(64 * sizeof(double));
+        d_ints = (int*)be.alloc(16 * sizeof(int));
+        be.memset0(d_red, 64 * sizeof(double));
+        be.memset0(d_ints, 16 * sizeof(int));
+        for (int v = 0; v < 5; ++v) cur[v] = nullptr;
+    }
+    ~Ctx() {
+        for (double* p : all_bufs) be.free(p);
+        for (double*& p : slot) be.free(p);
+        be.free(d_geo_rows);
+        be.free(d_geo_cols);
+        be.free(d_bx);
+        be.free(d_by);
+        be.free(d_bxq);
+        be.free(d_byq);
+        be.free(d_red);
+        be.free(d_series);
+        be.free(d_ints);
+        be.shutdown();
+    }
+
+    void set_model(const double* consts, int kind, double eta, const double* params) {
+        // ModelConsts order: R0 Ea K1 K2 K3 K4 DT Dl_max phi_l gamma_T Kd Sd Dd_max phi_d phi_T r_sp T_ref
+        if (kind != 1 && kind != 2) throw InvalidError("model_kind must be 1 or 2");
+        model.K1 = consts[2];
+        model.K2 = consts[3];
+        model.K3 = consts[4];
+        model.K4 = consts[5];
+        model.DT = consts[6];
+        model.Dl_max = consts[7];
+        model.phi_l = consts[8];
+        model.gamma_T = consts[9];
+        model.Kd = consts[10];
+        model.Sd = consts[11];
+        model.Dd_max = consts[12];
+        model.phi_d = consts[13];
+        model.phi_T = consts[14];
+        model.r_sp = consts[15];
+        model.T_shift = (kind == 2) ? consts[16] : 0.0;
+        model.eta = eta;
+        bool params_changed = false;
+        for (int k = 0; k < 8; ++k) {
+            const double v = params ? params[k] : 0.0;
+            if (std::memcmp(&v, &mp.p[k], sizeof(double)) != 0) params_changed = true;
+            mp.p[k] = v;
+        }
+        if (params_changed && d_bx) build_mms_tables();
+        fcp_time[0] = fcp_time[1] = NAN;  // cached forcing depends on the constants
+        last.have = false;
+    }
+
+    // ------------------------------------------------------------------ geometry
+    void build_geometry() {
+        std::vector<double> rows(4 * (size_t)nrows, 0.0), cols(4 * (size_t)ld, 0.0);
+        auto hx = [&](int i) { return xg[i] - xg[i - 1]; };
+        auto ky = [&](int j) { return yg[j] - yg[j - 1]; };
+        for (int l = 0; l < nrows; ++l) {
+            const int i = i0 + l;
+            if (i >= 1) {
+                rows[l] = 1.0 / hx(i);
+                rows[3 * (size_t)nrows + l] = hx(i);
+            }
+            if (i >= 1 && i <= N - 1) {
+                const double hm = (hx(i) + hx(i + 1)) * 0.5;
+                rows[(size_t)nrows + l] = 1.0 / hm;
+                rows[2 * (size_t)nrows + l] = hm;
+            }
+        }
+        for (int j = 0; j <= M; ++j) {
+            if (j >= 1) {
+                cols[j] = 1.0 / ky(j);
+                cols[3 * (size_t)ld + j] = ky(j);
+            }
+            if (j >= 1 && j <= M - 1) {
+                const double km = (ky(j) + ky(j + 1)) * 0.5;
+                cols[(size_t)ld + j] = 1.0 / km;
+                cols[2 * (size_t)ld + j] = km;
+            }
+        }
+        d_geo_rows = (double*)be.alloc(rows.size() * sizeof(double));
+        d_geo_cols = (double*)be.alloc(cols.size() * sizeof(double));
+        be.h2d(d_geo_rows, rows.data(), rows.size() * sizeof(double));
+        be.h2d(d_geo_cols, cols.data(), cols.size() * sizeof(double));
+        double cx = 0, cy = 0;
+        for (int i = 1; i <= N - 1; ++i) {
+            const double hm = (hx(i) + hx(i + 1)) * 0.5;
+            cx = std::max(cx, (1.0 / hx(i) + 1.0 / hx(i + 1)) / hm);
+        }
+        for (int j = 1; j <= M - 1; ++j) {
+            const double km = (ky(j) + ky(j + 1)) * 0.5;
+            cy = std::max(cy, (1.0 / ky(j) + 1.0 / ky(j + 1)) / km);
+        }
+        q_metric = cx + cy;
+    }
+    GridDev grid() const {
+        GridDev g;
+        g.nrows = nrows;
+        g.ncols = ncols;
+        g.ld = ld;
+        g.i0 = i0;
+        g.N = N;
+        g.M = M;
+        g.rh = d_geo_rows;
+        g.rhm = d_geo_rows + nrows;
+        g.hm = d_geo_rows + 2 * (size_t)nrows;
+        g.h = d_geo_rows + 3 * (size_t)nrows;
+        g.rk = d_geo_cols;
+        g.rkm = d_geo_cols + ld;
+        g.km = d_geo_cols + 2 * (size_t)ld;
+        g.k = d_geo_cols + 3 * (size_t)ld;
+        return g;
+    }
+    void build_mms_tables() {
+        be.free(d_bx);
+        be.free(d_by);
+        be.free(d_bxq);
+        be.free(d_byq);
+        d_bx = d_by = d_bxq = d_byq = nullptr;
+        if (mms_case == CASE_STREAM) return;
+        std::vector<double> nx, qx, ny, qy;
+        build_axis_tables(mms_case, mp, xg, i0, nrows, nrows, nx, qx);
+        build_axis_tables(mms_case, mp, yg, 0, ncols, ld, ny, qy);
+        auto up = [&](const std::vector<double>& v) {
+            double* d = (double*)be.alloc(std::max<size_t>(v.size(), 1) * sizeof(double));
+            if (!v.empty()) be.h2d(d, v.data(), v.size() * sizeof(double));
+            return d;
+        };
+        d_bx = up(nx);
+        d_by = up(ny);
+        d_bxq = up(qx);
+        d_byq = up(qy);
+    }
+    MmsTabs tabs() const { return MmsTabs{d_bx, d_by, d_bxq, d_byq, nrows, ld}; }
+    ForcingSrc forcing_src(double t, int which) {
+        ForcingSrc s;
+        s.tm = mms_time_fill(mms_case, model, mp, t);
+        for (int v = 0; v < 5; ++v) s.f[v] = nullptr;
+        if (mms_case == CASE_STREAM) {
+            if (!stream_forcing_set[which]) throw InvalidError("streamed forcing not set for this time level");
+            for (int v = 0; v < 5; ++v) s.f[v] = slot[(which ? SF10 : SF00) + v];
+        }
+        return s;
+    }
+
+    // ------------------------------------------------------------------ buffers
+    size_t field_elems() const { return (size_t)nrows * ld; }
+    double* new_field() {
+        double* p = (double*)be.alloc(field_elems() * sizeof(double));
+        be.memset0(p, field_elems() * sizeof(double));
+        return p;
+    }
+    double* B(int id) {
+        if (!slot[id]) slot[id] = new_field();
+        return slot[id];
+    }
+    double* acquire() {
+        double* p;
+        if (!free_bufs.empty()) {
+            p = free_bufs.back();
+            free_bufs.pop_back();
+        } else {
+            p = new_field();
+            all_bufs.push_back(p);
+        }
+        valid.erase(p);
+        return p;
+    }
+    void release(double* p) {
+        if (!p) return;
+        for (int v = 0; v < 5; ++v)
+            if (cur[v] == p) return;
+        if (std::find(free_bufs.begin(), free_bufs.end(), p) == free_bufs.end()) free_bufs.push_back(p);
+    }
+    void release_retained() {
+        std::vector<double*> r;
+        r.swap(retained);
+        for (double* p : r) release(p);
+    }
+    Range full() const { return Range{0, nrows}; }
+    Range owned() const { return Range{gl, nrows - gr}; }
+    Range shrink(Range r) const {
+        // one stencil application: rows next to a non-physical slab edge lose validity
+        Range o = r;
+        if (i0 + r.lo > 0) o.lo = r.lo + 1;
+        if (i0 + r.hi - 1 < N) o.hi = r.hi - 1;
+        return o;
+    }
+    Range vof(const double* p) const {
+        auto it = valid.find(p);
+        return it == valid.end() ? Range{0, 0} : it->second;
+    }
+    struct Use {
+        const double* p;
+        bool stencil;
+    };
+    Range need(std::initializer_list<Use> uses) const {
+        Range r = full();
+        for (const Use& u : uses) {
+            if (!u.p) continue;
+            Range v = vof(u.p);
+            if (u.stencil) v = shrink(v);
+            r.lo = std::max(r.lo, v.lo);
+            r.hi = std::min(r.hi, v.hi);
+        }
+        if (r.hi < r.lo) r.hi = r.lo;
+        return r;
+    }
+    void mark(double* p, Range r) { valid[p] = r; }
+
+    void upload_field(double* dst, const double* src) {
+        be.h2d_2d(dst, ld, src, ncols, ncols, nrows);
+        mark(dst, full());
+    }
+    void download_field(double* dst, const double* src) { be.d2h_2d(dst, ncols, src, ld, ncols, nrows); }
+
+    void require_state() const {
+        if (!cur[0]) throw InvalidError("state not set");
+    }
+    void reset_history() {
+        fcp_time[0] = fcp_time[1] = NAN;
+        last.have = false;
+        release_retained();
+    }
+    void ensure_state_buffers() {
+        for (int v = 0; v < 5; ++v)
+            if (!cur[v]) cur[v] = acquire();
+    }
+    void set_state(const double* const h[5]) {
+        ensure_state_buffers();
+        for (int v = 0; v < 5; ++v) upload_field(cur[v], h[v]);
+        reset_history();
+    }
+    void get_state(double* const h[5]) {
+        require_state();
+        for (int v = 0; v < 5; ++v)
+            if (h[v]) download_field(h[v], cur[v]);
+        be.sync();
+    }
+    // Install nxt as the state; buffers of the old state that are not reused go back to the pool.
+    void commit_state(double* const nxt[5]) {
+        Range o = owned();
+        for (int v = 0; v < 5; ++v) {
+            Range r = vof(nxt[v]);
+            if (r.lo > o.lo || r.hi < o.hi)
+                throw InvalidError("ghost depth too small for this step (stencil applications exceeded the ghost rows)");
+        }
+        double* old[5];
+        for (int v = 0; v < 5; ++v) {
+            old[v] = cur[v];
+            cur[v] = nxt[v];
+        }
+        for (int v = 0; v < 5; ++v) release(old[v]);
+    }
+    // The caller refreshed the ghost rows of the current state (halo exchange).
+    void mark_state_exchanged() {
+        require_state();
+        for (int v = 0; v < 5; ++v) mark(cur[v], full());
+    }
+
+    // ------------------------------------------------------------------ dispatch helpers
+    template <class Fn>
+    void dispatch(Fn&& fn) {
+        const int c = mms_case, r = react;
+#define TEDD_D(CC, RR)             \
+    if (c == CC && r == RR) {      \
+        fn.template run<CC, RR>(); \
+        return;                    \
+    }
+        TEDD_D(CASE_STREAM, REACT_CS3)
+        TEDD_D(CASE_STREAM, REACT_REG)
+        TEDD_D(CASE_POL, REACT_CS3)
+        TEDD_D(CASE_POL, REACT_REG)
+        TEDD_D(CASE_EXPSIN, REACT_CS3)
+        TEDD_D(CASE_EXPSIN, REACT_REG)
+        TEDD_D(CASE_PEAKS, REACT_CS3)
+        TEDD_D(CASE_PEAKS, REACT_REG)
+        TEDD_D(CASE_NFS, REACT_CS3)
+        TEDD_D(CASE_NFS, REACT_REG)
+#undef TEDD_D
+        throw InvalidError("unsupported case/reaction combination");
+    }
+
+    Fields5 fields(double* const p[5]) const {
+        Fields5 f;
+        for (int v = 0; v < 5; ++v) f.v[v] = p[v];
+        return f;
+    }
+    struct Tmp5 {  // five pool buffers handed back on scope exit
+        Ctx* c;
+        double* p[5];
+        explicit Tmp5(Ctx* c_) : c(c_) {
+            for (int v = 0; v < 5; ++v) p[v] = c->acquire();
+        }
+        ~Tmp5() {
+            for (int v = 0; v < 5; ++v) c->release(p[v]);
+        }
+    };
+
+    // ------------------------------------------------------------------ field evaluation / Euler
+    struct FieldOp {
+        Ctx* c;
+        double t, dt;
+        bool euler;
+        double* out[5];
+        template <int CASE, int REACT>
+        void run() {
+            Ctx& C = *c;
+            Range r = C.need({{C.cur[0], true}, {C.cur[1], true}, {C.cur[2], true}, {C.cur[3], true}, {C.cur[4], false}});
+            Out5 o;
+            for (int v = 0; v < 5; ++v) o.v[v] = out[v];
+            if (euler) {
+                FieldFn<CASE, REACT, true> f{C.grid(), C.model, C.tabs(), C.forcing_src(t, 0), C.fields(C.cur), o, dt};
+                C.be.nodes(FAM_FIELD, f, r.lo, r.hi, C.ncols);
+            } else {
+                FieldFn<CASE, REACT, false> f{C.grid(), C.model, C.tabs(), C.forcing_src(t, 0), C.fields(C.cur), o, dt};
+                C.be.nodes(FAM_FIELD, f, r.lo, r.hi, C.ncols);
+            }
+            for (int v = 0; v < 5; ++v) C.mark(out[v], r);
+        }
+    };
+    void eval_field(double t, double* const h[5]) {
+        require_state();
+        Tmp5 tmp(this);
+        FieldOp op{this, t, 0.0, false, {tmp.p[0], tmp.p[1], tmp.p[2], tmp.p[3], tmp.p[4]}};
+        dispatch(op);
+        for (int v = 0; v < 5; ++v)
+            if (h[v]) download_field(h[v], op.out[v]);
+        be.sync();
+    }
+    void step_feuler(double t0, double dt) {
+        require_state();
+        release_retained();
+        double* nxt[5];
+        for (int v = 0; v < 5; ++v) nxt[v] = acquire();
+        FieldOp op{this, t0, dt, true, {nxt[0], nxt[1], nxt[2], nxt[3], nxt[4]}};
+        dispatch(op);
+        commit_state(nxt);
+        last.have = false;
+        stream_forcing_set[0] = stream_forcing_set[1] = false;
+    }
+
+    // ------------------------------------------------------------------ hooks
+    struct ExactOp {
+        Ctx* c;
+        double t;
+        double* out[5];
+        template <int CASE, int REACT>
+        void run() {
+            Ctx& C = *c;
+            if (CASE == CASE_STREAM) throw InvalidError("no closed-form exact solution for streamed forcing");
+            Out5 o;
+            for (int v = 0; v < 5; ++v) o.v[v] = out[v];
+            ExactFn<(CASE == CASE_STREAM ? CASE_POL : CASE)> f{C.grid(), C.model, C.tabs(),
+                                                               mms_time_fill(C.mms_case, C.model, C.mp, t), o};
+            C.be.nodes(FAM_MISC, f, 0, C.nrows, C.ncols);
+            for (int v = 0; v < 5; ++v) C.mark(out[v], C.full());
+        }
+    };
+    void eval_exact(double t, double* const h[5]) {
+        Tmp5 tmp(this);
+        ExactOp op{this, t, {tmp.p[0], tmp.p[1], tmp.p[2], tmp.p[3], tmp.p[4]}};
+        dispatch(op);
+        for (int v = 0; v < 5; ++v)
+            if (h[v]) download_field(h[v], op.out[v]);
+        be.sync();
+    }
+    void set_state_exact(double t) {
+        ensure_state_buffers();
+        ExactOp op{this, t, {cur[0], cur[1], cur[2], cur[3], cur[4]}};
+        dispatch(op);
+        reset_history();
+    }
+    struct ForcingOp {
+        Ctx* c;
+        double t;
+        double* out[5];
+        template <int CASE, int REACT>
+        void run() {
+            Ctx& C = *c;
+            if (CASE == CASE_STREAM) throw InvalidError("forcing is streamed: nothing to evaluate");
+            Out5 o;
+            for (int v = 0; v < 5; ++v) o.v[v] = out[v];
+            ForcingFn<(CASE == CASE_STREAM ? CASE_POL : CASE), REACT> f{C.grid(), C.model, C.tabs(), C.forcing_src(t, 0), o};
+            C.be.nodes(FAM_MISC, f, 0, C.nrows, C.ncols);
+        }
+    };
+    void eval_forcing(double t, double* const h[5]) {
+        Tmp5 tmp(this);
+        ForcingOp op{this, t, {tmp.p[0], tmp.p[1], tmp.p[2], tmp.p[3], tmp.p[4]}};
+        dispatch(op);
+        for (int v = 0; v < 5; ++v)
+            if (h[v]) download_field(h[v], op.out[v]);
+        be.sync();
+    }
+    void eval_jacobian(int opid, double* const h[5]) {
+        require_state();
+        if (opid < 0 || opid > 5) throw InvalidError("jacobian op must be 0..5");
+        Tmp5 tmp(this);
+        Out5 o;
+        for (int v = 0; v < 5; ++v) o.v[v] = tmp.p[v];
+        Range r = need({{cur[0], true}, {cur[1], true}, {cur[2], true}, {cur[3], true}, {cur[4], false}});
+        if (react == REACT_REG) {
+            JacobianFn<REACT_REG> f{grid(), model, fields(cur), o, opid};
+            be.nodes(FAM_MISC, f, r.lo, r.hi, ncols);
+        } else {
+            JacobianFn<REACT_CS3> f{grid(), model, fields(cur), o, opid};
+            be.nodes(FAM_MISC, f, r.lo, r.hi, ncols);
+        }
+        for (int v = 0; v < 5; ++v)
+            if (h[v]) download_field(h[v], o.v[v]);
+        be.sync();
+    }
+    void set_forcing(int which, const double* const h[5]) {
+        if (mms_case != CASE_STREAM) throw InvalidError("context was created with a closed-form MMS case");
+        if (which != 0 && which != 1) throw InvalidError("which must be 0 or 1");
+        for (int v = 0; v < 5; ++v) upload_field(B((which ? SF10 : SF00) + v), h[v]);
+        stream_forcing_set[which] = true;
+    }
+
+    // ------------------------------------------------------------------ error norms
+    struct NormOp {
+        Ctx* c;
+        double t;
+        double* dev_out;
+        template <int CASE, int REACT>
+        void run() {
+            Ctx& C = *c;
+            ErrNormFn<CASE> f;
+            f.g = C.grid();
+            f.m = C.model;
+            f.tb = C.tabs();
+            f.tm = mms_time_fill(C.mms_case, C.model, C.mp, t);
+            f.S = C.fields(C.cur);
+            for (int v = 0; v < 5; ++v) f.ex[v] = (CASE == CASE_STREAM) ? C.slot[EX0 + v] : nullptr;
+            Range o = C.owned();
+            Range r = C.need({{C.cur[1], true}, {C.cur[2], true}, {C.cur[3], true}});
+            if ((C.gl > 0 || C.gr > 0) && (r.lo > o.lo || r.hi < o.hi))
+                throw InvalidError("ghost rows are stale: exchange them before taking norms");
+            C.be.nodes_sum(FAM_NORMS, f, o.lo, o.hi, C.ncols, dev_out);
+        }
+    };
+    void error_norms_async(double t, double* dev_out) {
+        require_state();
+        NormOp op{this, t, dev_out};
+        dispatch(op);
+    }
+    void error_norms(double t, const double* const exact[5], double* out8) {
+        require_state();
+        if (mms_case == CASE_STREAM) {
+            if (!exact) throw InvalidError("exact fields required when forcing is streamed");
+            for (int v = 0; v < 5; ++v) upload_field(B(EX0 + v), exact[v]);
+        }
+        error_norms_async(t, d_red + 32);
+        be.d2h(out8, d_red + 32, 8 * sizeof(double));
+        be.sync();
+    }
+
+    // ------------------------------------------------------------------ the predictor-corrector step
+    int auto_sweeps(double q, double tol, int cap) const {
+        // Jacobi on rows (2 + q_ij) d_ij - (off-diagonals summing to <= q_ij): contraction <= q/(2+q)
+        if (!(q > 0)) return 2;
+        const double rho = q / (2.0 + q);
+        const double s = std::ceil(std::log(tol) / std::log(rho)) + 1.0;
+        if (!(s < (double)cap)) return cap;
+        return std::max(2, (int)s);
+    }
+
+    struct StepParams {
+        double t0, dt;
+        int num_pc, num_newton, cs_iters;
+        double cs_rtol;
+        int sweeps[3];
+    };
+    struct PcOp {
+        Ctx* c;
+        StepParams p;
+        template <int CASE, int REACT>
+        void run() {
+            c->template step_pc_impl<CASE, REACT>(p);
+        }
+    };
+
+    void step_pc(double t0, double dt, int num_pc, int num_newton, int cs_iters, double cs_rtol,
+                 const int32_t* sweeps_in, double jtol, int jmax) {
+        require_state();
+        if (!(dt > 0)) throw AssertError("dt must be > 0");
+        if (num_pc < 0 || num_newton < 0) throw InvalidError("negative iteration counts");
+        if (cs_iters < 0 || cs_iters > 4096) throw InvalidError("cs_newton_iterations must be in [0, 4096]");
+        if (!(jtol > 0)) jtol = 1e-13;
+        if (jmax < 2) jmax = 2;
+        StepParams p{t0, dt, num_pc, num_newton, cs_iters, cs_rtol, {0, 0, 0}};
+        const double dcoef[3] = {model.DT, model.Dl_max, model.Dd_max};
+        for (int v = 0; v < 3; ++v) {
+            const int s = sweeps_in ? sweeps_in[v] : 0;
+            p.sweeps[v] = (s > 0) ? std::max(2, (int)s) : auto_sweeps(dt * std::fabs(dcoef[v]) * q_metric, jtol, jmax);
+        }
+        PcOp op{this, p};
+        dispatch(op);
+    }
+
+    template <int VAR, int CASE, int REACT>
+    void newton_solve(const StepParams& p, const ForcingSrc& f1, const NewtonIn& a, double* unew, int nsweeps, int slot_id) {
+        const GridDev g = grid();
+        double* rhs = B(RHS);
+        double* da = B(DA);
+        double* db = B(DB);
+        const int fam_rhs = (VAR == VAR_T) ? FAM_RHS_T : (VAR == VAR_CL) ? FAM_RHS_CL : FAM_RHS_CD;
+        const int fam_jac = (VAR == VAR_T) ? FAM_JACOBI_T : (VAR == VAR_CL) ? FAM_JACOBI_CL : FAM_JACOBI_CD;
+        Range r;
+        if (VAR == VAR_T)
+            r = need({{a.cp1, false}, {a.To, true}, {a.YT, false}});
+        else if (VAR == VAR_CL)
+            r = need({{a.cp1, true}, {a.To, true}, {a.clo, true}, {a.Tn, true}, {a.Ycl, false}});
+        else
+            r = need({{a.cp1, true}, {a.To, true}, {a.cdo, true}, {a.clo, false}, {a.cs1, false}, {a.Tn, true},
+                      {a.cln, false}, {a.Ycd, false}});
+        NewtonRhsFn<VAR, CASE, REACT> fr{g, model, tabs(), f1, a, rhs, da, p.dt};
+        be.nodes(fam_rhs, fr, r.lo, r.hi, ncols);
+        mark(rhs, r);
+        mark(da, r);
+        double* din = da;
+        double* dout = db;
+        for (int k = 2; k <= nsweeps; ++k) {
+            Range rk = need({{din, true}, {rhs, false}});
+            if (k < nsweeps) {
+                JacobiFn<VAR, REACT, false> fj{g, model, a, rhs, din, dout, p.dt};
+                be.nodes(fam_jac, fj, rk.lo, rk.hi, ncols);
+                mark(dout, rk);
+                std::swap(din, dout);
+            } else {
+                JacobiFn<VAR, REACT, true> fj{g, model, a, rhs, din, unew, p.dt};
+                be.nodes_max(fam_jac, fj, rk.lo, rk.hi, ncols, d_red + 2 * slot_id);
+                mark(unew, rk);
+            }
+        }
+    }
+
+    template <int CASE, int REACT>
+    void step_pc_impl(const StepParams& p) {
+        const GridDev g = grid();
+        const MmsTabs tb = tabs();
+        const double t0 = p.t0, dt = p.dt, t1 = p.t0 + p.dt;
+        const ForcingSrc f0 = forcing_src(t0, 0), f1 = forcing_src(t1, 1);
+        release_retained();
+        be.memset0(d_red, 8 * sizeof(double));
+
+        // cp-forcing cell averages: reuse the array the last step computed for this time level
+        const double* fcp_t0 = nullptr;
+        const double* fcp_t1 = nullptr;
+        double* fcp_t0_out = nullptr;
+        double* fcp_t1_out = nullptr;
+        if (CASE != CASE_STREAM) {
+            int k0 = -1;
+            for (int k = 0; k < 2; ++k) {
+                const Range v = vof(B(FCPA + k)), o = owned();
+                if (fcp_time[k] == t0 && v.lo <= o.lo && v.hi >= o.hi) k0 = k;
+            }
+            if (k0 >= 0) {
+                fcp_t0 = B(FCPA + k0);
+            } else {
+                k0 = 0;
+                fcp_t0_out = B(FCPA + k0);
+            }
+            const int k1 = 1 - k0;
+            fcp_t1_out = B(FCPA + k1);
+            fcp_time[k0] = t0;
+            fcp_time[k1] = t1;
+        }
+
+        double* YT = B(Y0);
+        double* Ycl = B(Y0 + 1);
+        double* Ycd = B(Y0 + 2);
+        std::vector<double*> temps;  // everything acquired during this step
+        auto grab = [&]() {
+            double* q = acquire();
+            temps.push_back(q);
+            return q;
+        };
+        double* cpP = grab();
+        double* csP = grab();
+        {
+            Range r = need({{cur[0], true}, {cur[1], true}, {cur[2], true}, {cur[3], true}, {cur[4], false},
+                            {fcp_t0, false}});
+            PredictFn<CASE, REACT> f{g, model, tb, f0, f1, fields(cur), YT, Ycl, Ycd, cpP, csP, fcp_t0, fcp_t0_out,
+                                     fcp_t1_out, dt};
+            be.nodes(FAM_PREDICT, f, r.lo, r.hi, ncols);
+            for (double* q : {YT, Ycl, Ycd, cpP, csP}) mark(q, r);
+            if (fcp_t0_out) {
+                mark(fcp_t0_out, r);
+                fcp_t0 = fcp_t0_out;
+            }
+            if (fcp_t1_out) {
+                mark(fcp_t1_out, r);
+                fcp_t1 = fcp_t1_out;
+            }
+        }
+
+        // iterate: Newton on T -> cl -> cd with cp, cs frozen, then correct cp, cs
+        double* To = cur[VAR_T];
+        double* clo = cur[VAR_CL];
+        double* cdo = cur[VAR_CD];
+        double* cpU = cpP;  // cp, cs the Newton steps use
+        double* csU = csP;
+        double* cp_last_used = nullptr;
+        double* cs_last_used = nullptr;
+        for (int pc = 0; pc < p.num_pc; ++pc) {
+            for (int nw = 0; nw < p.num_newton; ++nw) {
+                double* Tn = grab();
+                double* cln = grab();
+                double* cdn = grab();
+                NewtonIn a;
+                a.cp1 = cpU;
+                a.cs1 = csU;
+                a.To = To;
+                a.clo = clo;
+                a.cdo = cdo;
+                a.Tn = Tn;
+                a.cln = cln;
+                a.YT = YT;
+                a.Ycl = Ycl;
+                a.Ycd = Ycd;
+                newton_solve<VAR_T, CASE, REACT>(p, f1, a, Tn, p.sweeps[0], 0);
+                newton_solve<VAR_CL, CASE, REACT>(p, f1, a, cln, p.sweeps[1], 1);
+                newton_solve<VAR_CD, CASE, REACT>(p, f1, a, cdn, p.sweeps[2], 2);
+                To = Tn;
+                clo = cln;
+                cdo = cdn;
+                cp_last_used = cpU;
+                cs_last_used = csU;
+            }
+            double* cpN = grab();
+            double* csN = grab();
+            CorrectIn<CASE, REACT> ci{g, model, tb, f0, f1, fields(cur), To, clo, cdo, fcp_t0, fcp_t1, dt};
+            Range r = need({{cur[0], false}, {cur[1], false}, {cur[2], false}, {cur[3], false}, {cur[4], false},
+                            {To, false}, {clo, false}, {cdo, false}, {fcp_t0, false}, {fcp_t1, false}});
+            be.template correct<CASE, REACT>(ci, r.lo, r.hi, ncols, cpN, csN, p.cs_iters, p.cs_rtol, d_ints);
+            mark(cpN, r);
+            mark(csN, r);
+            cpU = cpN;
+            csU = csN;
+        }
+
+        double* nxt[5] = {cpU, To, clo, cdo, csU};
+        commit_state(nxt);
+        // keep what tedd_get_residuals needs; hand everything else back
+        last.have = (cp_last_used != nullptr);
+        last.t1 = t1;
+        last.dt = dt;
+        last.cp_used = cp_last_used;
+        last.cs_used = cs_last_used;
+        for (double* q : temps) {
+            if (q == cp_last_used || q == cs_last_used) {
+                bool is_state = false;
+                for (int v = 0; v < 5; ++v) is_state = is_state || (cur[v] == q);
+                if (!is_state) retained.push_back(q);
+            } else {
+                release(q);
+            }
+        }
+        for (int v = 0; v < 3; ++v) last.sweeps[v] = p.sweeps[v];
+        last.cs_iters_requested = p.cs_iters;
+        last.cs_newton_ran = (REACT == REACT_REG) && p.num_pc > 0;
+        stream_forcing_set[0] = stream_forcing_set[1] = false;
+    }
+
+    // ------------------------------------------------------------------ residuals of the last step
+    struct ResOp {
+        Ctx* c;
+        double* out[3];
+        template <int CASE, int REACT>
+        void run() {
+            Ctx& C = *c;
+            const GridDev g = C.grid();
+            ForcingSrc f1;
+            f1.tm = mms_time_fill(C.mms_case, C.model, C.mp, C.last.t1);
+            for (int v = 0; v < 5; ++v) f1.f[v] = (CASE == CASE_STREAM) ? C.slot[SF10 + v] : nullptr;
+            const double *cp = C.last.cp_used, *cs = C.last.cs_used;
+            const double *T1 = C.cur[VAR_T], *cl1 = C.cur[VAR_CL], *cd1 = C.cur[VAR_CD];
+            const double *YT = C.slot[Y0], *Ycl = C.slot[Y0 + 1], *Ycd = C.slot[Y0 + 2];
+            Range r = C.need({{cp, true}, {T1, true}, {cl1, true}, {cd1, true}, {cs, false}, {YT, false},
+                              {Ycl, false}, {Ycd, false}});
+            ResidualFn<VAR_T, CASE, REACT> a{g, C.model, C.tabs(), f1, cp, cs, T1, cl1, cd1, YT, out[0], C.last.dt};
+            ResidualFn<VAR_CL, CASE, REACT> b{g, C.model, C.tabs(), f1, cp, cs, T1, cl1, cd1, Ycl, out[1], C.last.dt};
+            ResidualFn<VAR_CD, CASE, REACT> d{g, C.model, C.tabs(), f1, cp, cs, T1, cl1, cd1, Ycd, out[2], C.last.dt};
+            C.be.nodes(FAM_RESIDUAL, a, r.lo, r.hi, C.ncols);
+            C.be.nodes(FAM_RESIDUAL, b, r.lo, r.hi, C.ncols);
+            C.be.nodes(FAM_RESIDUAL, d, r.lo, r.hi, C.ncols);
+        }
+    };
+    void get_residuals(double* const h[3]) {
+        if (!last.have) throw InvalidError("no predictor-corrector step has been taken since the state was set");
+        Tmp5 tmp(this);
+        for (int v = 0; v < 3; ++v) be.memset0(tmp.p[v], field_elems() * sizeof(double));
+        ResOp op{this, {tmp.p[0], tmp.p[1], tmp.p[2]}};
+        dispatch(op);
+        for (int v = 0; v < 3; ++v)
+            if (h[v]) download_field(h[v], op.out[v]);
+        be.sync();
+    }
+
+    void get_stats(tedd_step_stats* s) {
+        double red[8];
+        int ints[4];
+        be.d2h(red, d_red, 8 * sizeof(double));
+        be.d2h(ints, d_ints, 4 * sizeof(int));
+        be.sync();
+        for (int v = 0; v < 3; ++v) {
+            s->sweeps[v] = last.sweeps[v];
+            s->last_update[v] = red[2 * v];
+            s->increment[v] = red[2 * v + 1];
+        }
+        s->cs_iterations = last.cs_newton_ran ? ints[0] : 0;
+    }
+
+    // ------------------------------------------------------------------ multi-step with fused norms
+    void advance(double t0, double dt, int nsteps, int integrator, int num_pc, int num_newton, int cs_iters,
+                 double cs_rtol, const int32_t* sweeps, double jtol, int jmax, double* series) {
+        require_state();
+        if (nsteps < 0) throw InvalidError("nsteps < 0");
+        if (mms_case == CASE_STREAM) throw InvalidError("tedd_advance needs a closed-form MMS case");
+        if ((gl > 0 || gr > 0) && nsteps > 1)
+            throw InvalidError("tedd_advance on a partial slab: exchange ghost rows between steps instead");
+        const size_t need_elems = (size_t)(nsteps + 1) * 8;
+        if (series && need_elems > series_cap) {
+            be.free(d_series);
+            d_series = (double*)be.alloc(need_elems * sizeof(double));
+            series_cap = need_elems;
+        }
+        double t = t0;
+        if (series) error_norms_async(t, d_series);
+        for (int k = 0; k < nsteps; ++k) {
+            if (integrator == 0)
+                step_feuler(t, dt);
+            else
+                step_pc(t, dt, num_pc, num_newton, cs_iters, cs_rtol, sweeps, jtol, jmax);
+            t += dt;
+            if (series) error_norms_async(t, d_series + (size_t)(k + 1) * 8);
+        }
+        if (series) be.d2h(series, d_series, need_elems * sizeof(double));
+        be.sync();
+    }
+};
+
+}  // namespace tedd

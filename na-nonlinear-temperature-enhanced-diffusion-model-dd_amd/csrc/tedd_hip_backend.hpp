@@ -1,0 +1,407 @@
+// HIP execution backend for gfx950: memory, streams, kernel launchers over the node functors,
+// wave64 shuffle reductions, and the cs-corrector kernel with the reference's global early
+// exit.  One thread updates one node; a 256-thread workgroup covers 4 rows x 64 columns so
+// that each wavefront reads 64 consecutive doubles (512 B) of a row.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "tedd_ctx.hpp"
+
+namespace tedd {
+
+#define TEDD_HIP(call)                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            throw std::runtime_error(std::string(#call) + " failed: " + hipGetErrorString(e_));    \
+    } while (0)
+
+constexpr int kTileX = 64, kTileY = 4, kMaxReduceBlocks = 2048;
+
+template <class F>
+__global__ void __launch_bounds__(256) k_nodes(const F f, int r0, int r1, int ncols) {
+    const int j = blockIdx.x * kTileX + threadIdx.x;
+    const int li = r0 + blockIdx.y * kTileY + threadIdx.y;
+    if (j < ncols && li < r1) f(li, j);
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double o = __shfl_xor(v, off, 64);
+        v = (o > v || o != o) ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double o = __shfl_xor(v, off, 64);
+        v = (o < v) ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// max-reduction of non-negative values: grid-stride over 4x64 tiles, one atomic per block and slot
+template <class F>
+__global__ void __launch_bounds__(256) k_nodes_max(const F f, int r0, int r1, int ncols, int tiles_x, int ntiles,
+                                                  unsigned long long* out) {
+    double red[F::NR];
+#pragma unroll
+    for (int k = 0; k < F::NR; ++k) red[k] = 0.0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int j = (t % tiles_x) * kTileX + threadIdx.x;
+        const int li = r0 + (t / tiles_x) * kTileY + threadIdx.y;
+        if (j < ncols && li < r1) f(li, j, red);
+    }
+    __shared__ double sm[4][F::NR];
+    const int wave = threadIdx.y, lane = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < F::NR; ++k) {
+        const double v = wave_max(red[k]);
+        if (lane == 0) sm[wave][k] = v;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < F::NR) {
+        double v = sm[0][lane];
+        for (int w = 1; w < 4; ++w) v = (sm[w][lane] > v || sm[w][lane] != sm[w][lane]) ? sm[w][lane] : v;
+        if (v != v) v = INFINITY;
+        atomicMax(out + lane, (unsigned long long)__double_as_longlong(v));
+    }
+}
+
+// sum-reduction, deterministic: per-block partials, then a fixed-order final pass
+template <class F>
+__global__ void __launch_bounds__(256) k_nodes_sum(const F f, int r0, int r1, int ncols, int tiles_x, int ntiles,
+                                                  double* partials) {
+    double red[F::NR];
+#pragma unroll
+    for (int k = 0; k < F::NR; ++k) red[k] = 0.0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int j = (t % tiles_x) * kTileX + threadIdx.x;
+        const int li = r0 + (t / tiles_x) * kTileY + threadIdx.y;
+        if (j < ncols && li < r1) f(li, j, red);
+    }
+    __shared__ double sm[4][F::NR];
+    const int wave = threadIdx.y, lane = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < F::NR; ++k) {
+        const double v = wave_sum(red[k]);
+        if (lane == 0) sm[wave][k] = v;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < F::NR)
+        partials[(size_t)blockIdx.x * F::NR + lane] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+}
+__global__ void k_sum_final(const double* partials, int nblocks, int nr, double* out) {
+    const int k = threadIdx.x;
+    if (k >= nr) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * nr + k];
+    out[k] = s;
+}
+
+// ---- cs corrector (RegHCsTriple): cp trapezoid + per-node scalar Newton for cs with the
+// per-iteration global record  max|dx_k|, min|x_k|  that decides the reference's early exit
+// (src/prob1base.py:3654-3663: stop after iteration k when max|dx| < rtol |x| at every node).
+__global__ void k_cs_init(unsigned long long* gmax, unsigned long long* gmin, int iters) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < iters) {
+        gmax[k] = 0ull;
+        gmin[k] = 0x7FF0000000000000ull;  // +inf
+    }
+}
+template <int CASE>
+__global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_REG> a, int r0, int r1, int ncols,
+                                                  int tiles_x, int ntiles, double* cp_out, double* cs_out, int iters,
+                                                  const int* keep_ptr, unsigned long long* gmax,
+                                                  unsigned long long* gmin) {
+    extern __shared__ unsigned long long sm[];  // [iters] max bits, [iters] min bits
+    const int tid = threadIdx.y * kTileX + threadIdx.x;
+    const bool record = (keep_ptr == nullptr);
+    int keep = iters;
+    if (!record) {
+        keep = *keep_ptr;          // second pass: only if the global test stopped the iteration early
+        if (keep >= iters) return;
+    } else {
+        for (int k = tid; k < iters; k += 256) {
+            sm[k] = 0ull;
+            sm[iters + k] = 0x7FF0000000000000ull;
+        }
+        __syncthreads();
+    }
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int j = (t % tiles_x) * kTileX + threadIdx.x;
+        const int li = r0 + (t / tiles_x) * kTileY + threadIdx.y;
+        const bool active = (j < ncols && li < r1);
+        double x = 0.0, y = 0.0, av = 0.0;
+        bool in = false;
+        size_t c = 0;
+        if (active) {
+            c = at(a.g, li, j);
+            in = is_interior(a.g, li, j);
+            if (record) cp_out[c] = corrector_cp(a, li, j);
+            cs_newton_inputs(a, li, j, y, av, x);
+        }
+        for (int k = 0; k < keep; ++k) {
+            double adx = 0.0, ax = INFINITY;
+            if (active) {
+                const double dx = cs_newton_step(x, y, av, a.m.eta);
+                x = x + dx;
+                adx = fabs(dx);
+                ax = fabs(x);
+                if (adx != adx) adx = INFINITY;
+                if (ax != ax) ax = 0.0;
+            }
+            if (record) {
+                const double wmx = wave_max(adx), wmn = wave_min(ax);
+                if (threadIdx.x == 0) {
+                    atomicMax(&sm[k], (unsigned long long)__double_as_longlong(wmx));
+                    atomicMin(&sm[iters + k], (unsigned long long)__double_as_longlong(wmn));
+                }
+            }
+        }
+        if (active) cs_out[c] = in ? x : 0.0 * x;
+    }
+    if (record) {
+        __syncthreads();
+        for (int k = tid; k < iters; k += 256) {
+            atomicMax(gmax + k, sm[k]);
+            atomicMin(gmin + k, sm[iters + k]);
+        }
+    }
+}
+__global__ void k_cs_decide(const unsigned long long* gmax, const unsigned long long* gmin, int iters, double rtol,
+                            int* out_keep) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int keep = iters;
+    for (int k = 0; k < iters; ++k) {
+        const double mx = __longlong_as_double((long long)gmax[k]);
+        const double mn = __longlong_as_double((long long)gmin[k]);
+        if (mx < rtol * mn) {
+            keep = k + 1;
+            break;
+        }
+    }
+    out_keep[0] = keep;
+}
+
+// closed-form correctors (CsTriple): plain node functor
+template <int CASE, int REACT>
+struct CorrectClosedFn {
+    CorrectIn<CASE, REACT> a;
+    double *cp_out, *cs_out;
+    __device__ void operator()(int li, int j) const {
+        const size_t c = at(a.g, li, j);
+        cp_out[c] = corrector_cp(a, li, j);
+        cs_out[c] = corrector_cs_closed_form(a, li, j);
+    }
+};
+
+struct HipBackend {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int device = -1;
+    double* d_partials = nullptr;
+    unsigned long long* d_csstats = nullptr;  // [4096] max, [4096] min
+    bool profiling = false;
+    struct Rec {
+        int fam;
+        hipEvent_t a, b;
+    };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> event_pool;
+    double fam_ms[FAM_COUNT] = {0};
+    long long fam_n[FAM_COUNT] = {0};
+
+    void init(int dev) {
+        int cur = 0;
+        TEDD_HIP(hipGetDevice(&cur));
+        device = (dev >= 0) ? dev : cur;
+        TEDD_HIP(hipSetDevice(device));
+        TEDD_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        own_stream = true;
+        d_partials = (double*)alloc((size_t)kMaxReduceBlocks * 8 * sizeof(double));
+        d_csstats = (unsigned long long*)alloc(2 * 4096 * sizeof(unsigned long long));
+    }
+    void shutdown() {
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (Rec& r : recs) {
+            (void)hipEventDestroy(r.a);
+            (void)hipEventDestroy(r.b);
+        }
+        for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
+        free(d_partials);
+        free(d_csstats);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+    void set_stream(void* s) {
+        if (own_stream && stream) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+        }
+        stream = (hipStream_t)s;
+        own_stream = false;
+    }
+    void use_device() { TEDD_HIP(hipSetDevice(device)); }
+    void* alloc(size_t bytes) {
+        void* p = nullptr;
+        TEDD_HIP(hipMalloc(&p, bytes));
+        return p;
+    }
+    void free(void* p) {
+        if (p) (void)hipFree(p);
+    }
+    void memset0(void* p, size_t bytes) { TEDD_HIP(hipMemsetAsync(p, 0, bytes, stream)); }
+    void h2d(void* d, const void* s, size_t bytes) {
+        TEDD_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream));
+        TEDD_HIP(hipStreamSynchronize(stream));  // the source may be a temporary
+    }
+    void d2h(void* d, const void* s, size_t bytes) { TEDD_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream)); }
+    void h2d_2d(double* d, size_t dpitch, const double* s, size_t spitch, int width, int rows) {
+        TEDD_HIP(hipMemcpy2DAsync(d, dpitch * sizeof(double), s, spitch * sizeof(double), (size_t)width * sizeof(double),
+                                  rows, hipMemcpyHostToDevice, stream));
+        TEDD_HIP(hipStreamSynchronize(stream));
+    }
+    void d2h_2d(double* d, size_t dpitch, const double* s, size_t spitch, int width, int rows) {
+        TEDD_HIP(hipMemcpy2DAsync(d, dpitch * sizeof(double), s, spitch * sizeof(double), (size_t)width * sizeof(double),
+                                  rows, hipMemcpyDeviceToHost, stream));
+    }
+    void sync() { TEDD_HIP(hipStreamSynchronize(stream)); }
+
+    // ---- timing record
+    hipEvent_t get_event() {
+        if (!event_pool.empty()) {
+            hipEvent_t e = event_pool.back();
+            event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        TEDD_HIP(hipEventCreate(&e));
+        return e;
+    }
+    struct Scope {
+        HipBackend* b;
+        int fam;
+        hipEvent_t a{}, e{};
+        Scope(HipBackend* b_, int fam_) : b(b_), fam(fam_) {
+            if (b->profiling) {
+                a = b->get_event();
+                e = b->get_event();
+                (void)hipEventRecord(a, b->stream);
+            }
+        }
+        ~Scope() {
+            if (b->profiling) {
+                (void)hipEventRecord(e, b->stream);
+                b->recs.push_back(Rec{fam, a, e});
+            }
+        }
+    };
+    void profile_enable(bool on) {
+        profile_collect();
+        for (int f = 0; f < FAM_COUNT; ++f) {
+            fam_ms[f] = 0;
+            fam_n[f] = 0;
+        }
+        profiling = on;
+    }
+    void profile_collect() {
+        if (recs.empty()) return;
+        TEDD_HIP(hipStreamSynchronize(stream));
+        for (Rec& r : recs) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+                fam_ms[r.fam] += ms;
+                fam_n[r.fam] += 1;
+            }
+            event_pool.push_back(r.a);
+            event_pool.push_back(r.b);
+        }
+        recs.clear();
+    }
+
+    // ---- launchers
+    static void check_range(int r0, int r1, int ncols) {
+        if (r1 < r0 || ncols <= 0) throw std::runtime_error("bad launch range");
+    }
+    template <class F>
+    void nodes(int fam, const F& f, int r0, int r1, int ncols) {
+        check_range(r0, r1, ncols);
+        if (r1 == r0) return;
+        Scope sc(this, fam);
+        dim3 block(kTileX, kTileY), grid((ncols + kTileX - 1) / kTileX, (r1 - r0 + kTileY - 1) / kTileY);
+        hipLaunchKernelGGL(k_nodes<F>, grid, block, 0, stream, f, r0, r1, ncols);
+        TEDD_HIP(hipGetLastError());
+    }
+    static void tiling(int r0, int r1, int ncols, int& tiles_x, int& ntiles, int& nblocks) {
+        tiles_x = (ncols + kTileX - 1) / kTileX;
+        const long long nt = (long long)tiles_x * ((r1 - r0 + kTileY - 1) / kTileY);
+        if (nt > 0x7fffffffLL) throw std::runtime_error("mesh too large for the tile index");
+        ntiles = (int)nt;
+        nblocks = ntiles < kMaxReduceBlocks ? ntiles : kMaxReduceBlocks;
+    }
+    template <class F>
+    void nodes_max(int fam, const F& f, int r0, int r1, int ncols, double* dev_out) {
+        check_range(r0, r1, ncols);
+        if (r1 == r0) return;
+        Scope sc(this, fam);
+        int tx, nt, nb;
+        tiling(r0, r1, ncols, tx, nt, nb);
+        hipLaunchKernelGGL(k_nodes_max<F>, dim3(nb), dim3(kTileX, kTileY), 0, stream, f, r0, r1, ncols, tx, nt,
+                           (unsigned long long*)dev_out);
+        TEDD_HIP(hipGetLastError());
+    }
+    template <class F>
+    void nodes_sum(int fam, const F& f, int r0, int r1, int ncols, double* dev_out) {
+        check_range(r0, r1, ncols);
+        Scope sc(this, fam);
+        if (r1 == r0) {
+            memset0(dev_out, F::NR * sizeof(double));
+            return;
+        }
+        int tx, nt, nb;
+        tiling(r0, r1, ncols, tx, nt, nb);
+        hipLaunchKernelGGL(k_nodes_sum<F>, dim3(nb), dim3(kTileX, kTileY), 0, stream, f, r0, r1, ncols, tx, nt, d_partials);
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64), 0, stream, d_partials, nb, (int)F::NR, dev_out);
+        TEDD_HIP(hipGetLastError());
+    }
+    template <int CASE, int REACT>
+    void correct(const CorrectIn<CASE, REACT>& a, int r0, int r1, int ncols, double* cp_out, double* cs_out, int iters,
+                 double rtol, int* d_keep) {
+        check_range(r0, r1, ncols);
+        if (r1 == r0) return;
+        if constexpr (REACT == REACT_CS3) {
+            CorrectClosedFn<CASE, REACT> f{a, cp_out, cs_out};
+            nodes(FAM_CORRECT, f, r0, r1, ncols);
+        } else {
+            Scope sc(this, FAM_CS_NEWTON);
+            int tx, nt, nb;
+            tiling(r0, r1, ncols, tx, nt, nb);
+            unsigned long long* gmax = d_csstats;
+            unsigned long long* gmin = d_csstats + 4096;
+            const size_t lds = (size_t)(iters > 0 ? 2 * iters : 2) * sizeof(unsigned long long);
+            if (iters > 0) hipLaunchKernelGGL(k_cs_init, dim3((iters + 255) / 256), dim3(256), 0, stream, gmax, gmin, iters);
+            hipLaunchKernelGGL(k_cs_newton<CASE>, dim3(nb), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx, nt,
+                               cp_out, cs_out, iters, (const int*)nullptr, gmax, gmin);
+            hipLaunchKernelGGL(k_cs_decide, dim3(1), dim3(1), 0, stream, gmax, gmin, iters, rtol, d_keep);
+            if (iters > 1)
+                hipLaunchKernelGGL(k_cs_newton<CASE>, dim3(nb), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx,
+                                   nt, cp_out, cs_out, iters, (const int*)d_keep, gmax, gmin);
+            TEDD_HIP(hipGetLastError());
+        }
+    }
+};
+
+}  // namespace tedd

@@ -1,0 +1,356 @@
+// Pointwise arithmetic of the hot path: constitutive laws, the reghcstriple reaction, the
+// 5-point flux-form stencil pieces, Jacobian stencil coefficients, MMS exact solutions and
+// forcing terms.  Every function is `__host__ __device__` so that the HIP kernels and the
+// host-compiled test twin (tests/cpu_twin) execute the same source.
+//
+// Reference semantics restated here (file:line into the reference's src/):
+//   model laws            prob1base.py:96-217
+//   reaction term         prob1base.py:2489-2509, 3452-3466, 3592-3593, 2875-2876
+//   F* right-hand sides   prob1base.py:2599-2672
+//   Jacobian stencils     prob1base.py:2511-2597, 2674-2839
+//   MMS forcing           prob1base.py:2313-2425, 3503-3551
+//   MMS exact solutions   prob1_mms_cases.py:151-337, 406-511
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define TEDD_HD __host__ __device__ __forceinline__
+#else
+#define TEDD_HD inline
+#endif
+
+namespace tedd {
+
+enum : int { CASE_STREAM = -1, CASE_POL = 0, CASE_EXPSIN = 1, CASE_PEAKS = 2, CASE_NFS = 3 };
+enum : int { REACT_CS3 = 0, REACT_REG = 1 };
+enum : int { VAR_CP = 0, VAR_T = 1, VAR_CL = 2, VAR_CD = 3, VAR_CS = 4 };
+
+constexpr double kPi = 3.14159265358979323846;
+
+// Model constants as the kernels use them.  T_shift = T_ref for DefaultModel02 and 0 for
+// DefaultModel01 (prob1base.py:209-217).
+struct ModelC {
+    double K1, K2, K3, K4, DT, Dl_max, phi_l, gamma_T, Kd, Sd, Dd_max, phi_d, phi_T, r_sp, T_shift;
+    double eta;
+};
+
+// ---------------------------------------------------------------- constitutive laws
+TEDD_HD double law_Dl(const ModelC& m, double c) { return m.Dl_max * exp(-m.phi_l * c); }
+TEDD_HD double law_V1(const ModelC& m, double T) { return m.gamma_T * T; }
+
+// Dd(c,T) = Dd_max e^{-phi_d c} e^{-phi_T/(T+T_shift)}, and 0 where T+T_shift == 0.
+TEDD_HD double law_Dd(const ModelC& m, double c, double T) {
+    const double Te = T + m.T_shift;
+    return (Te != 0.0) ? m.Dd_max * exp(-m.phi_d * c - m.phi_T / Te) : 0.0;
+}
+// dDd/dT = Dd phi_T/(T+T_shift)^2
+TEDD_HD double law_dDd_dT(const ModelC& m, double c, double T) {
+    const double Te = T + m.T_shift;
+    return (Te != 0.0) ? m.Dd_max * exp(-m.phi_d * c - m.phi_T / Te) * (m.phi_T / (Te * Te)) : 0.0;
+}
+
+TEDD_HD double heaviside_reg(double x, double eta) { return 1.0 / (1.0 + exp(-eta * x)); }
+
+template <int REACT>
+TEDD_HD double reaction_gain(const ModelC& m, double cs) {
+    if (REACT == REACT_REG) return heaviside_reg(cs, m.eta);
+    return cs;
+}
+// R = Kd g(cs) (1+cl) (Sd-cd)   (interior nodes only; callers apply the mask)
+template <int REACT>
+TEDD_HD double reaction(const ModelC& m, double cl, double cd, double cs) {
+    return (1.0 + cl) * (m.Sd - cd) * (m.Kd * reaction_gain<REACT>(m, cs));
+}
+
+// ---------------------------------------------------------------- geometry at a node
+// Reciprocal metrics at node (i,j): rhw=1/h_i, rhe=1/h_{i+1}, rhm=1/hm_i, rks=1/k_j,
+// rkn=1/k_{j+1}, rkm=1/km_j.  Only meaningful on interior nodes.
+struct Geo {
+    double rhw, rhe, rhm, rks, rkn, rkm;
+};
+struct St5 {  // a field at the node and its four neighbours: c=(i,j) e=(i+1,j) w=(i-1,j) n=(i,j+1) s=(i,j-1)
+    double c, e, w, n, s;
+};
+struct Face4 {  // a face coefficient on the four faces of the node's cell
+    double w, e, s, n;
+};
+struct Coef5 {  // one row of a 5-point Jacobian: dF_ij/du at c, e, w, n, s
+    double c, e, w, n, s;
+};
+
+TEDD_HD Face4 faces_const(double v) { return Face4{v, v, v, v}; }
+
+TEDD_HD Face4 faces_Dl(const ModelC& m, const St5& cp) {
+    return Face4{law_Dl(m, 0.5 * (cp.c + cp.w)), law_Dl(m, 0.5 * (cp.e + cp.c)),
+                 law_Dl(m, 0.5 * (cp.c + cp.s)), law_Dl(m, 0.5 * (cp.n + cp.c))};
+}
+TEDD_HD Face4 faces_Dd(const ModelC& m, const St5& cp, const St5& T) {
+    return Face4{law_Dd(m, 0.5 * (cp.c + cp.w), 0.5 * (T.c + T.w)),
+                 law_Dd(m, 0.5 * (cp.e + cp.c), 0.5 * (T.e + T.c)),
+                 law_Dd(m, 0.5 * (cp.c + cp.s), 0.5 * (T.c + T.s)),
+                 law_Dd(m, 0.5 * (cp.n + cp.c), 0.5 * (T.n + T.c))};
+}
+TEDD_HD Face4 faces_dDd_dT(const ModelC& m, const St5& cp, const St5& T) {
+    return Face4{law_dDd_dT(m, 0.5 * (cp.c + cp.w), 0.5 * (T.c + T.w)),
+                 law_dDd_dT(m, 0.5 * (cp.e + cp.c), 0.5 * (T.e + T.c)),
+                 law_dDd_dT(m, 0.5 * (cp.c + cp.s), 0.5 * (T.c + T.s)),
+                 law_dDd_dT(m, 0.5 * (cp.n + cp.c), 0.5 * (T.n + T.c))};
+}
+
+// D*x(D D-x u) + D*y(D D-y u) at an interior node
+TEDD_HD double div_flux(const Geo& g, const Face4& D, const St5& u) {
+    const double qw = D.w * ((u.c - u.w) * g.rhw), qe = D.e * ((u.e - u.c) * g.rhe);
+    const double qs = D.s * ((u.c - u.s) * g.rks), qn = D.n * ((u.n - u.c) * g.rkn);
+    return (qe - qw) * g.rhm + (qn - qs) * g.rkm;
+}
+// -D*x(Mx(V1(T)(cl+1)))  (V2 == 0)
+TEDD_HD double div_advection(const ModelC& m, const Geo& g, const St5& T, const St5& cl) {
+    const double vc = law_V1(m, T.c) * (cl.c + 1.0);
+    const double ve = law_V1(m, T.e) * (cl.e + 1.0);
+    const double vw = law_V1(m, T.w) * (cl.w + 1.0);
+    return -((0.5 * (ve + vc) - 0.5 * (vc + vw)) * g.rhm);
+}
+
+// interior parts of the right-hand sides (forcing added by the caller)
+TEDD_HD double rhs_cp(const ModelC& m, double cp, double T, double cl) {
+    return -m.K1 * (cl + 1.0) * cp - m.K2 * T * cp;
+}
+TEDD_HD double rhs_T(const ModelC& m, const Geo& g, const St5& T, double cp) {
+    return div_flux(g, faces_const(m.DT), T) - m.K3 * cp * T.c;
+}
+TEDD_HD double rhs_cl(const ModelC& m, const Geo& g, const Face4& Dl, const St5& T, const St5& cl, double cp) {
+    return div_flux(g, Dl, cl) + div_advection(m, g, T, cl) - m.K4 * cp * (cl.c + 1.0);
+}
+TEDD_HD double rhs_cd_diffusion(const Geo& g, const Face4& Dd, const St5& cd) { return div_flux(g, Dd, cd); }
+
+// ---------------------------------------------------------------- Jacobian rows
+// Diffusion part: u -> D*x(D D-x u)+D*y(D D-y u)
+TEDD_HD Coef5 jac_diffusion(const Geo& g, const Face4& D) {
+    Coef5 r;
+    r.w = D.w * (g.rhm * g.rhw);
+    r.e = D.e * (g.rhm * g.rhe);
+    r.s = D.s * (g.rkm * g.rks);
+    r.n = D.n * (g.rkm * g.rkn);
+    r.c = -(r.w + r.e + r.s + r.n);
+    return r;
+}
+// dFT/dT  (prob1base.py:2674-2684)
+TEDD_HD Coef5 jac_T_FT(const ModelC& m, const Geo& g, double cp) {
+    Coef5 r = jac_diffusion(g, faces_const(m.DT));
+    r.c -= m.K3 * cp;
+    return r;
+}
+// dFcl/dcl (prob1base.py:2716-2750).  w_ok/e_ok are 0 where node (i-1,j)/(i+1,j) is a boundary node.
+TEDD_HD Coef5 jac_cl_Fcl(const ModelC& m, const Geo& g, const Face4& Dl, const St5& T, double cp,
+                         double w_ok, double e_ok) {
+    Coef5 r = jac_diffusion(g, Dl);
+    r.w += w_ok * (0.5 * g.rhm) * law_V1(m, T.w);
+    r.e -= e_ok * (0.5 * g.rhm) * law_V1(m, T.e);
+    r.c -= m.K4 * cp;
+    return r;
+}
+// dFcl/dT  (prob1base.py:2686-2714): only the x-advection couples
+TEDD_HD Coef5 jac_T_Fcl(const ModelC& m, const Geo& g, const St5& cl, double w_ok, double e_ok) {
+    Coef5 r;
+    r.c = 0.0;
+    r.n = 0.0;
+    r.s = 0.0;
+    r.w = w_ok * (1.0 + cl.w) * m.gamma_T * (0.5 * g.rhm);
+    r.e = -(e_ok * (1.0 + cl.e) * m.gamma_T * (0.5 * g.rhm));
+    return r;
+}
+// dFcd/dT  (prob1base.py:2752-2800); dDdT = dDd/dT on the faces
+TEDD_HD Coef5 jac_T_Fcd(const Geo& g, const Face4& dDdT, const St5& cd) {
+    const double gw = ((cd.c - cd.w) * g.rhw) * dDdT.w, ge = ((cd.e - cd.c) * g.rhe) * dDdT.e;
+    const double gs = ((cd.c - cd.s) * g.rks) * dDdT.s, gn = ((cd.n - cd.c) * g.rkn) * dDdT.n;
+    Coef5 r;
+    r.w = -(0.5 * g.rhm) * gw;
+    r.e = (0.5 * g.rhm) * ge;
+    r.s = -(0.5 * g.rkm) * gs;
+    r.n = (0.5 * g.rkm) * gn;
+    r.c = r.w + r.e + r.s + r.n;
+    return r;
+}
+// dFcd/dcl: diagonal only (prob1base.py:2802-2809, 2541-2568)
+template <int REACT>
+TEDD_HD double jac_cl_Fcd_diag(const ModelC& m, double cd, double cs) {
+    return (m.Sd - cd) * (m.Kd * reaction_gain<REACT>(m, cs));
+}
+// dFcd/dcd (prob1base.py:2811-2839, 2570-2597)
+template <int REACT>
+TEDD_HD Coef5 jac_cd_Fcd(const ModelC& m, const Geo& g, const Face4& Dd, double cl, double cs) {
+    Coef5 r = jac_diffusion(g, Dd);
+    r.c -= (1.0 + cl) * (m.Kd * reaction_gain<REACT>(m, cs));
+    return r;
+}
+
+// ---------------------------------------------------------------- MMS exact solutions
+// Values of the exact solution and the derivatives the forcing terms need, at one point.
+struct MmsPt {
+    double cp, cp_t, cp_x, cp_y;
+    double T, T_t, T_x, T_y, T_l;
+    double cl, cl_t, cl_x, cl_y, cl_l;
+    double cd, cd_t, cd_x, cd_y, cd_l;
+    double cs, cs_t;
+};
+// Case-specific scalars that depend on time only; filled on the host per time level.
+struct MmsTime {
+    double s[12];
+};
+// 1-D tables of the basis functions each case is built from, at the nodes (bx: [nb][nrows],
+// by: [nb][ld]) and at the 3 Gauss abscissae of each node's cell (bxq: [nbq][3][nrows],
+// byq: [nbq][3][ld]).  Rows are local (slab) rows.
+struct MmsTabs {
+    const double* bx;
+    const double* by;
+    const double* bxq;
+    const double* byq;
+    int nrows;
+    int ld;
+};
+TEDD_HD double tab_x(const MmsTabs& t, int k, int li) { return t.bx[(size_t)k * t.nrows + li]; }
+TEDD_HD double tab_y(const MmsTabs& t, int k, int j) { return t.by[(size_t)k * t.ld + j]; }
+TEDD_HD double tab_xq(const MmsTabs& t, int k, int a, int li) { return t.bxq[((size_t)k * 3 + a) * t.nrows + li]; }
+TEDD_HD double tab_yq(const MmsTabs& t, int k, int b, int j) { return t.byq[((size_t)k * 3 + b) * t.ld + j]; }
+
+constexpr int mms_num_basis(int c) { return c == CASE_POL ? 2 : c == CASE_EXPSIN ? 2 : c == CASE_PEAKS ? 3 : c == CASE_NFS ? 15 : 0; }
+constexpr int mms_num_qbasis(int c) { return c == CASE_POL ? 1 : c == CASE_EXPSIN ? 1 : c == CASE_PEAKS ? 2 : c == CASE_NFS ? 3 : 0; }
+
+TEDD_HD void mms_set_all(MmsPt& p, double u, double ut, double ux, double uy, double lap) {
+    p.cp = p.T = p.cl = p.cd = p.cs = u;
+    p.cp_t = p.T_t = p.cl_t = p.cd_t = p.cs_t = ut;
+    p.cp_x = p.T_x = p.cl_x = p.cd_x = ux;
+    p.cp_y = p.T_y = p.cl_y = p.cd_y = uy;
+    p.T_l = p.cl_l = p.cd_l = lap;
+}
+
+// ExpSin pieces shared by node and quadrature evaluation.  tm.s: 0 e^{-at}, 1 e^{-t}, 2 a,
+// 3 beta, 4 beta', 5 -K1 t, 6 q0, 7 q1, 8 q2  with  cp = W exp(-K1 t + beta W),
+// cs = r_sp W exp(q0 + q1 W + q2 W^2).
+TEDD_HD double expsin_cp(const MmsTime& tm, double W) { return W * exp(tm.s[5] + tm.s[3] * W); }
+
+template <int CASE>
+TEDD_HD MmsPt mms_node(const ModelC& m, const MmsTime& tm, const MmsTabs& tb, int li, int j) {
+    MmsPt p;
+    if (CASE == CASE_POL) {  // u = X(x) X(y)/(1+t), X = x(1-x); basis 0: X, 1: X'
+        const double fx = tab_x(tb, 0, li), dfx = tab_x(tb, 1, li);
+        const double fy = tab_y(tb, 0, j), dfy = tab_y(tb, 1, j);
+        const double phi = tm.s[0], dphi = tm.s[1];
+        mms_set_all(p, phi * fx * fy, dphi * fx * fy, phi * dfx * fy, phi * fx * dfy,
+                    phi * (-2.0 * fy - 2.0 * fx));
+    } else if (CASE == CASE_PEAKS) {  // u = C e^{-at} (x^2+y^2)^3 sin(pi x) sin(pi y); basis 0 sin, 1 cos, 2 x
+        const double sx = tab_x(tb, 0, li), cx = tab_x(tb, 1, li), x = tab_x(tb, 2, li);
+        const double sy = tab_y(tb, 0, j), cy = tab_y(tb, 1, j), y = tab_y(tb, 2, j);
+        const double amp = tm.s[0];
+        const double R = x * x + y * y, S = sx * sy, R2 = R * R, R3 = R * R * R;
+        const double u = amp * R3 * S;
+        const double ux = amp * (6.0 * x * R2 * S + R3 * kPi * cx * sy);
+        const double uy = amp * (6.0 * y * R2 * S + R3 * kPi * sx * cy);
+        const double uxx = amp * (6.0 * R2 * S + 24.0 * x * x * R * S + 12.0 * x * R2 * kPi * cx * sy - kPi * kPi * R3 * S);
+        const double uyy = amp * (6.0 * R2 * S + 24.0 * y * y * R * S + 12.0 * y * R2 * kPi * sx * cy - kPi * kPi * R3 * S);
+        mms_set_all(p, u, tm.s[1] * u, ux, uy, uxx + uyy);
+    } else if (CASE == CASE_NFS) {  // u_v = f_v(x) f_v(y)/(1+t); basis 3v+d: d-th derivative of f_v
+        const double phi = tm.s[0], dphi = tm.s[1];
+        double u[5], ut[5], ux[5], uy[5], ul[5];
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            const double fx = tab_x(tb, 3 * v, li), dfx = tab_x(tb, 3 * v + 1, li), ddfx = tab_x(tb, 3 * v + 2, li);
+            const double fy = tab_y(tb, 3 * v, j), dfy = tab_y(tb, 3 * v + 1, j), ddfy = tab_y(tb, 3 * v + 2, j);
+            u[v] = phi * fx * fy;
+            ut[v] = dphi * fx * fy;
+            ux[v] = phi * dfx * fy;
+            uy[v] = phi * fx * dfy;
+            ul[v] = phi * (ddfx * fy + fx * ddfy);
+        }
+        p.cp = u[0]; p.cp_t = ut[0]; p.cp_x = ux[0]; p.cp_y = uy[0];
+        p.T = u[1]; p.T_t = ut[1]; p.T_x = ux[1]; p.T_y = uy[1]; p.T_l = ul[1];
+        p.cl = u[2]; p.cl_t = ut[2]; p.cl_x = ux[2]; p.cl_y = uy[2]; p.cl_l = ul[2];
+        p.cd = u[3]; p.cd_t = ut[3]; p.cd_x = ux[3]; p.cd_y = uy[3]; p.cd_l = ul[3];
+        p.cs = u[4]; p.cs_t = ut[4];
+    } else {  // CASE_EXPSIN; basis 0 sin(pi x), 1 cos(pi x)
+        const double sx = tab_x(tb, 0, li), cx = tab_x(tb, 1, li);
+        const double sy = tab_y(tb, 0, j), cy = tab_y(tb, 1, j);
+        const double W = sx * sy, Wx = kPi * cx * sy, Wy = kPi * sx * cy, lapW = -2.0 * kPi * kPi * W;
+        const double ea = tm.s[0], e1 = tm.s[1], a = tm.s[2], beta = tm.s[3], dbeta = tm.s[4];
+        p.T = ea * W; p.T_t = -a * ea * W; p.T_x = ea * Wx; p.T_y = ea * Wy; p.T_l = ea * lapW;
+        p.cl = -e1 * W; p.cl_t = e1 * W; p.cl_x = -e1 * Wx; p.cl_y = -e1 * Wy; p.cl_l = -e1 * lapW;
+        p.cd = e1 * W; p.cd_t = -e1 * W; p.cd_x = e1 * Wx; p.cd_y = e1 * Wy; p.cd_l = e1 * lapW;
+        const double E = exp(tm.s[5] + beta * W);
+        const double cpW = E * (1.0 + beta * W);
+        p.cp = W * E;
+        p.cp_t = p.cp * (-m.K1 + dbeta * W);
+        p.cp_x = cpW * Wx;
+        p.cp_y = cpW * Wy;
+        const double cs = m.r_sp * W * exp(tm.s[6] + tm.s[7] * W + tm.s[8] * W * W);
+        p.cs = cs;
+        p.cs_t = cs * (-m.Kd * (m.Sd - e1 * W) * (1.0 - e1 * W));
+    }
+    return p;
+}
+
+// Pointwise cp-forcing  d_t cp + cp (K1 (1+cl) + K2 T)  of the exact solution at the Gauss point
+// (a,b) of node (li,j)'s cell  (prob1base.py:2313-2323).
+template <int CASE>
+TEDD_HD double mms_fcp_quad(const ModelC& m, const MmsTime& tm, const MmsTabs& tb, int li, int a, int j, int b) {
+    double cp, cp_t, cl, T;
+    if (CASE == CASE_POL) {
+        const double ff = tab_xq(tb, 0, a, li) * tab_yq(tb, 0, b, j);
+        cp = cl = T = tm.s[0] * ff;
+        cp_t = tm.s[1] * ff;
+    } else if (CASE == CASE_PEAKS) {
+        const double x = tab_xq(tb, 1, a, li), y = tab_yq(tb, 1, b, j);
+        const double R = x * x + y * y;
+        const double u = tm.s[0] * (R * R * R) * (tab_xq(tb, 0, a, li) * tab_yq(tb, 0, b, j));
+        cp = cl = T = u;
+        cp_t = tm.s[1] * u;
+    } else if (CASE == CASE_NFS) {  // q-basis 0,1,2: f_cp, f_T, f_cl
+        const double fcp = tab_xq(tb, 0, a, li) * tab_yq(tb, 0, b, j);
+        cp = tm.s[0] * fcp;
+        cp_t = tm.s[1] * fcp;
+        T = tm.s[0] * (tab_xq(tb, 1, a, li) * tab_yq(tb, 1, b, j));
+        cl = tm.s[0] * (tab_xq(tb, 2, a, li) * tab_yq(tb, 2, b, j));
+    } else {
+        const double W = tab_xq(tb, 0, a, li) * tab_yq(tb, 0, b, j);
+        cp = expsin_cp(tm, W);
+        cp_t = cp * (-m.K1 + tm.s[4] * W);
+        cl = -tm.s[1] * W;
+        T = tm.s[0] * W;
+    }
+    return cp_t - (-cp * (m.K1 * (1.0 + cl) + m.K2 * T));
+}
+
+// 3x3 Gauss-Legendre cell average of the pointwise cp-forcing (prob1base.py:493-598).
+template <int CASE>
+TEDD_HD double mms_fcp_cellavg(const ModelC& m, const MmsTime& tm, const MmsTabs& tb, int li, int j) {
+    const double w[3] = {5.0 / 9.0, 8.0 / 9.0, 5.0 / 9.0};
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc += w[a] * w[b] * mms_fcp_quad<CASE>(m, tm, tb, li, a, j, b);
+    return 0.25 * acc;
+}
+
+// Nodal forcing terms from the exact solution (prob1base.py:2331-2425, 3503-3551).
+TEDD_HD double mms_fT(const ModelC& m, const MmsPt& p) { return p.T_t - (m.DT * p.T_l - m.K3 * p.cp * p.T); }
+TEDD_HD double mms_fcl(const ModelC& m, const MmsPt& p) {
+    const double Dl = law_Dl(m, p.cp), dDl = -m.phi_l * Dl;
+    return p.cl_t - (dDl * (p.cp_x * p.cl_x + p.cp_y * p.cl_y) + Dl * p.cl_l - law_V1(m, p.T) * p.cl_x -
+                     (p.cl + 1.0) * (m.gamma_T * p.T_x) - m.K4 * p.cp * (p.cl + 1.0));
+}
+template <int REACT>
+TEDD_HD double mms_fcd(const ModelC& m, const MmsPt& p) {
+    const double Te = p.T + m.T_shift;
+    const double Dd = law_Dd(m, p.cp, p.T);
+    const double dc = -m.phi_d * Dd;
+    const double dT = (Te != 0.0) ? Dd * (m.phi_T / (Te * Te)) : 0.0;
+    return p.cd_t - ((dc * p.cp_x + dT * p.T_x) * p.cd_x + (dc * p.cp_y + dT * p.T_y) * p.cd_y + Dd * p.cd_l +
+                     m.Kd * (m.Sd - p.cd) * (p.cl + 1.0) * reaction_gain<REACT>(m, p.cs));
+}
+template <int REACT>
+TEDD_HD double mms_fcs(const ModelC& m, const MmsPt& p) {
+    return p.cs_t - (-m.Kd * reaction_gain<REACT>(m, p.cs) * (1.0 + p.cl) * (m.Sd - p.cd));
+}
+
+}  // namespace tedd

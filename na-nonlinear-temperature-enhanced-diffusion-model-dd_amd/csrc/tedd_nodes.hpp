@@ -1,0 +1,598 @@
+// Per-node bodies of the kernels of the predictor-corrector step.  Each functor's
+// operator()(li, j) updates local row li, column j.  The HIP launchers (tedd_kernels.hip) map
+// one thread to one node; the host-compiled test twin loops over nodes with the same bodies.
+//
+// Reference sequencing restated (file:line into the reference's src/prob1base.py):
+//   step driver 3117-3149, Heun predictors 2953-2965 / 3631-3645 / 3174-3188,
+//   Newton steps T/cl/cd 2998-3115, correctors 2967-2996 / 3665-3702 / 3190-3219,
+//   forward Euler 2885-2903, error norms 387-433 and mms_trial_utils.py:81-110.
+#pragma once
+#include "tedd_math.hpp"
+
+namespace tedd {
+
+// Local (slab) view of the mesh.  Rows are local: global i = i0 + li.
+struct GridDev {
+    int nrows, ncols, ld, i0, N, M;
+    const double* rh;   // [nrows] 1/h_i   (0 at global i = 0)
+    const double* rhm;  // [nrows] 1/hm_i  (0 at global i = 0, N)
+    const double* rk;   // [ld]    1/k_j   (0 at j = 0)
+    const double* rkm;  // [ld]    1/km_j  (0 at j = 0, M)
+    const double* hm;   // [nrows] hm_i (0 at i = 0, N)  -- norm weights
+    const double* km;   // [ld]
+    const double* h;    // [nrows] h_i (0 at i = 0)
+    const double* k;    // [ld]
+};
+
+TEDD_HD bool is_interior(const GridDev& g, int li, int j) {
+    const int i = g.i0 + li;
+    return i >= 1 && i <= g.N - 1 && j >= 1 && j <= g.M - 1;
+}
+TEDD_HD size_t at(const GridDev& g, int li, int j) { return (size_t)li * g.ld + j; }
+TEDD_HD Geo geo_at(const GridDev& g, int li, int j) {
+    return Geo{g.rh[li], g.rh[li + 1], g.rhm[li], g.rk[j], g.rk[j + 1], g.rkm[j]};
+}
+TEDD_HD St5 load5(const double* u, const GridDev& g, int li, int j) {
+    const size_t c = at(g, li, j);
+    return St5{u[c], u[c + g.ld], u[c - g.ld], u[c + 1], u[c - 1]};
+}
+
+struct Fields5 {  // cp, T, cl, cd, cs
+    const double* v[5];
+};
+struct Out5 {
+    double* v[5];
+};
+
+// Where the forcing terms come from: closed-form MMS evaluation (CASE >= 0) or arrays the
+// caller uploaded (CASE_STREAM): f[0..4] = cell-averaged fcp, fT, fcl, fcd, fcs.
+struct ForcingSrc {
+    MmsTime tm;
+    const double* f[5];
+};
+
+struct Forcing5 {
+    double fcp, fT, fcl, fcd, fcs;
+};
+
+// All five forcing values at a node.  Unused members are dead-code-eliminated after inlining.
+template <int CASE, int REACT>
+TEDD_HD Forcing5 node_forcing(const ModelC& m, const MmsTabs& tb, const ForcingSrc& src, const GridDev& g,
+                              int li, int j, bool interior, bool want_fcp) {
+    Forcing5 r;
+    if (CASE == CASE_STREAM) {
+        const size_t c = at(g, li, j);
+        r.fcp = src.f[0][c];
+        r.fT = src.f[1][c];
+        r.fcl = src.f[2][c];
+        r.fcd = src.f[3][c];
+        r.fcs = src.f[4][c];
+    } else {
+        const MmsPt p = mms_node<CASE>(m, src.tm, tb, li, j);
+        r.fT = mms_fT(m, p);
+        r.fcl = mms_fcl(m, p);
+        r.fcd = mms_fcd<REACT>(m, p);
+        r.fcs = mms_fcs<REACT>(m, p);
+        r.fcp = (interior && want_fcp) ? mms_fcp_cellavg<CASE>(m, src.tm, tb, li, j) : 0.0;
+    }
+    return r;
+}
+
+struct F5 {
+    double cp, T, cl, cd, cs;
+};
+
+// The semi-discrete field F(S, t) at a node given the forcing values (prob1base.py:2599-2672).
+template <int REACT>
+TEDD_HD F5 node_field(const ModelC& m, const GridDev& g, const Fields5& S, const Forcing5& f, int li, int j,
+                      bool interior) {
+    F5 F{f.fcp, f.fT, f.fcl, f.fcd, 0.0};
+    if (interior) {
+        const Geo ge = geo_at(g, li, j);
+        const St5 cp = load5(S.v[VAR_CP], g, li, j), T = load5(S.v[VAR_T], g, li, j);
+        const St5 cl = load5(S.v[VAR_CL], g, li, j), cd = load5(S.v[VAR_CD], g, li, j);
+        const double cs = S.v[VAR_CS][at(g, li, j)];
+        const double R = reaction<REACT>(m, cl.c, cd.c, cs);
+        F.cp += rhs_cp(m, cp.c, T.c, cl.c);
+        F.T += rhs_T(m, ge, T, cp.c);
+        F.cl += rhs_cl(m, ge, faces_Dl(m, cp), T, cl, cp.c);
+        F.cd += rhs_cd_diffusion(ge, faces_Dd(m, cp, T), cd) + R;
+        F.cs = f.fcs - R;
+    }
+    return F;
+}
+
+// ------------------------------------------------------------------------------------
+// K_F: field evaluation only (parity hook and forward Euler).  out = F, or S + dt F.
+template <int CASE, int REACT, bool EULER>
+struct FieldFn {
+    GridDev g;
+    ModelC m;
+    MmsTabs tb;
+    ForcingSrc f0;
+    Fields5 S;
+    Out5 out;
+    double dt;
+    TEDD_HD void operator()(int li, int j) const {
+        const bool in = is_interior(g, li, j);
+        const Forcing5 f = node_forcing<CASE, REACT>(m, tb, f0, g, li, j, in, true);
+        const F5 F = node_field<REACT>(m, g, S, f, li, j, in);
+        const size_t c = at(g, li, j);
+        if (EULER) {
+            out.v[0][c] = S.v[0][c] + dt * F.cp;
+            out.v[1][c] = S.v[1][c] + dt * F.T;
+            out.v[2][c] = S.v[2][c] + dt * F.cl;
+            out.v[3][c] = S.v[3][c] + dt * F.cd;
+            out.v[4][c] = S.v[4][c] + dt * F.cs;
+        } else {
+            out.v[0][c] = F.cp;
+            out.v[1][c] = F.T;
+            out.v[2][c] = F.cl;
+            out.v[3][c] = F.cd;
+            out.v[4][c] = F.cs;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// K_pred: Y_v = dt F_v(S0,t0) + 2 v0 for v in {T,cl,cd}; Heun predictors for cp and cs.
+// fcp_t0 (optional): cell-averaged cp-forcing at t0 computed by the previous step;
+// fcp_t1 (optional): where to keep the one at t1 for the corrector and the next step.
+template <int CASE, int REACT>
+struct PredictFn {
+    GridDev g;
+    ModelC m;
+    MmsTabs tb;
+    ForcingSrc f0, f1;
+    Fields5 S;
+    double *YT, *Ycl, *Ycd, *cp1, *cs1;
+    const double* fcp_t0;
+    double* fcp_t0_out;
+    double* fcp_t1_out;
+    double dt;
+    TEDD_HD void operator()(int li, int j) const {
+        const bool in = is_interior(g, li, j);
+        const size_t c = at(g, li, j);
+        Forcing5 fa = node_forcing<CASE, REACT>(m, tb, f0, g, li, j, in, fcp_t0 == nullptr);
+        if (CASE != CASE_STREAM && fcp_t0 != nullptr) fa.fcp = fcp_t0[c];
+        const F5 F = node_field<REACT>(m, g, S, fa, li, j, in);
+        const double cp0 = S.v[VAR_CP][c], T0 = S.v[VAR_T][c], cl0 = S.v[VAR_CL][c], cd0 = S.v[VAR_CD][c],
+                     cs0 = S.v[VAR_CS][c];
+        YT[c] = dt * F.T + 2.0 * T0;
+        Ycl[c] = dt * F.cl + 2.0 * cl0;
+        Ycd[c] = dt * F.cd + 2.0 * cd0;
+        // forcing at t1: only fcp (cell average) and fcs are needed here
+        double fcp1, fcs1;
+        if (CASE == CASE_STREAM) {
+            fcp1 = f1.f[0][c];
+            fcs1 = f1.f[4][c];
+        } else {
+            const MmsPt p1 = mms_node<CASE>(m, f1.tm, tb, li, j);
+            fcs1 = mms_fcs<REACT>(m, p1);
+            fcp1 = in ? mms_fcp_cellavg<CASE>(m, f1.tm, tb, li, j) : 0.0;
+            if (fcp_t0_out) fcp_t0_out[c] = fa.fcp;
+            if (fcp_t1_out) fcp_t1_out[c] = fcp1;
+        }
+        // Heun for cp (other fields frozen at t0)
+        const double cps = cp0 + dt * F.cp;
+        const double Fcps = fcp1 + (in ? rhs_cp(m, cps, T0, cl0) : 0.0);
+        cp1[c] = cp0 + 0.5 * dt * (F.cp + Fcps);
+        // Heun for cs
+        const double css = cs0 + dt * F.cs;
+        const double Fcss = in ? (fcs1 - reaction<REACT>(m, cl0, cd0, css)) : 0.0;
+        const double v = cs0 + (0.5 * dt) * (F.cs + Fcss);
+        cs1[c] = (REACT == REACT_REG) ? (in ? v : 0.0 * v) : v;
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// Newton systems (2 I - dt J_v) delta = rhs_v,  v in {T, cl, cd}, Jacobians at the lagged
+// state S' = (cp1, T_old, cl_old, cd_old, cs1).
+
+struct NewtonIn {
+    const double *cp1, *cs1;           // predicted (or last corrected) cp, cs
+    const double *To, *clo, *cdo;      // lagged T, cl, cd
+    const double *Tn, *cln;            // new T (for cl, cd systems), new cl (for the cd system)
+    const double *YT, *Ycl, *Ycd;
+};
+
+// One row of (2 I - dt J_v): returns diag and the off-diagonal multipliers of delta at e,w,n,s
+// written so that  delta_c = (rhs + oe*d_e + ow*d_w + on*d_n + os*d_s) / diag.
+// For v = cd the reference assembles the (0,-1) coefficients on the (i-1,j) diagonal and the
+// (-1,0) ones on the (i,j-1) diagonal (prob1base.py:3097,3099); that is reproduced here.
+template <int VAR, int REACT>
+TEDD_HD void newton_row(const ModelC& m, const GridDev& g, const NewtonIn& a, int li, int j, double dt,
+                        double& diag, double& oe, double& ow, double& on, double& os) {
+    const Geo ge = geo_at(g, li, j);
+    const size_t c = at(g, li, j);
+    Coef5 r;
+    if (VAR == VAR_T) {
+        r = jac_T_FT(m, ge, a.cp1[c]);
+    } else if (VAR == VAR_CL) {
+        const St5 cp = load5(a.cp1, g, li, j);
+        St5 T;
+        T.c = 0.0; T.n = 0.0; T.s = 0.0;
+        T.e = a.To[c + g.ld];
+        T.w = a.To[c - g.ld];
+        r = jac_cl_Fcl(m, ge, faces_Dl(m, cp), T, cp.c, 1.0, 1.0);
+    } else {
+        const St5 cp = load5(a.cp1, g, li, j), T = load5(a.To, g, li, j);
+        r = jac_cd_Fcd<REACT>(m, ge, faces_Dd(m, cp, T), a.clo[c], a.cs1[c]);
+        const double t = r.w;  // reference quirk: W and S coefficients exchanged in the cd matrix
+        r.w = r.s;
+        r.s = t;
+    }
+    diag = 2.0 - dt * r.c;
+    oe = dt * r.e;
+    ow = dt * r.w;
+    on = dt * r.n;
+    os = dt * r.s;
+}
+
+// K_rhs: right-hand side of the Newton system for v and the first Jacobi iterate
+// delta^1 = rhs/diag (the iterate after one sweep from delta^0 = 0).
+template <int VAR, int CASE, int REACT>
+struct NewtonRhsFn {
+    GridDev g;
+    ModelC m;
+    MmsTabs tb;
+    ForcingSrc f1;
+    NewtonIn a;
+    double* rhs;
+    double* d1;
+    double dt;
+    TEDD_HD void operator()(int li, int j) const {
+        const size_t c = at(g, li, j);
+        if (!is_interior(g, li, j)) {
+            rhs[c] = 0.0;
+            d1[c] = 0.0;
+            return;
+        }
+        const Geo ge = geo_at(g, li, j);
+        double fv;
+        if (CASE == CASE_STREAM) {
+            fv = f1.f[VAR][c];
+        } else {
+            const MmsPt p = mms_node<CASE>(m, f1.tm, tb, li, j);
+            fv = (VAR == VAR_T) ? mms_fT(m, p) : (VAR == VAR_CL) ? mms_fcl(m, p) : mms_fcd<REACT>(m, p);
+        }
+        double r;
+        if (VAR == VAR_T) {
+            const St5 T = load5(a.To, g, li, j);
+            r = a.YT[c] - (2.0 * T.c - dt * (fv + rhs_T(m, ge, T, a.cp1[c])));
+        } else if (VAR == VAR_CL) {
+            const St5 cp = load5(a.cp1, g, li, j), T = load5(a.To, g, li, j), cl = load5(a.clo, g, li, j);
+            const double F = fv + rhs_cl(m, ge, faces_Dl(m, cp), T, cl, cp.c);
+            // coupling  dt * (dFcl/dT) (Tn - To), boundary entries of (Tn - To) dropped
+            const int i = g.i0 + li;
+            const double w_ok = (i > 1) ? 1.0 : 0.0, e_ok = (i < g.N - 1) ? 1.0 : 0.0;
+            const Coef5 k = jac_T_Fcl(m, ge, cl, w_ok, e_ok);
+            const double ww = a.Tn[c - g.ld] - T.w, we = a.Tn[c + g.ld] - T.e;
+            r = a.Ycl[c] - 2.0 * cl.c + dt * F + dt * (k.e * we + k.w * ww);
+        } else {
+            const St5 cp = load5(a.cp1, g, li, j), T = load5(a.To, g, li, j), cd = load5(a.cdo, g, li, j);
+            const double clc = a.clo[c], csc = a.cs1[c];
+            const double F = fv + rhs_cd_diffusion(ge, faces_Dd(m, cp, T), cd) + reaction<REACT>(m, clc, cd.c, csc);
+            // coupling with (Tn - To) keeps the boundary entries of the increment
+            const Coef5 k = jac_T_Fcd(ge, faces_dDd_dT(m, cp, T), cd);
+            const St5 Tn = load5(a.Tn, g, li, j);
+            const double JTw = k.c * (Tn.c - T.c) + k.e * (Tn.e - T.e) + k.w * (Tn.w - T.w) + k.n * (Tn.n - T.n) +
+                               k.s * (Tn.s - T.s);
+            const double Jclw = jac_cl_Fcd_diag<REACT>(m, cd.c, csc) * (a.cln[c] - clc);
+            r = a.Ycd[c] - 2.0 * cd.c + dt * F + dt * JTw + dt * Jclw;
+        }
+        double diag, oe, ow, on, os;
+        newton_row<VAR, REACT>(m, g, a, li, j, dt, diag, oe, ow, on, os);
+        rhs[c] = r;
+        d1[c] = r / diag;
+    }
+};
+
+// K_jacobi: one matrix-free Jacobi sweep; coefficients are rebuilt from the lagged fields.
+// FINAL: write the updated unknown u_new = u_old + delta instead of delta (boundary rule:
+// T -> 0, cl/cd keep their boundary values, prob1base.py:3038-3039, 2102-2106) and report
+// { max|delta_new - delta_in|, max|delta_new| } for the convergence record.
+template <int VAR, int REACT, bool FINAL>
+struct JacobiFn {
+    GridDev g;
+    ModelC m;
+    NewtonIn a;
+    const double* rhs;
+    const double* din;
+    double* out;
+    double dt;
+    static constexpr int NR = 2;
+    TEDD_HD void operator()(int li, int j, double* red) const {
+        const size_t c = at(g, li, j);
+        const double* uo = (VAR == VAR_T) ? a.To : (VAR == VAR_CL) ? a.clo : a.cdo;
+        if (!is_interior(g, li, j)) {
+            const int i = g.i0 + li;
+            const bool global_bd = (i == 0 || i == g.N || j == 0 || j == g.M);
+            if (FINAL) out[c] = (VAR == VAR_T && global_bd) ? 0.0 : uo[c];
+            else out[c] = 0.0;
+            return;
+        }
+        double diag, oe, ow, on, os;
+        newton_row<VAR, REACT>(m, g, a, li, j, dt, diag, oe, ow, on, os);
+        const double dn =
+            (rhs[c] + oe * din[c + g.ld] + ow * din[c - g.ld] + on * din[c + 1] + os * din[c - 1]) / diag;
+        if (FINAL) {
+            out[c] = uo[c] + dn;
+            const double up = fabs(dn - din[c]), mag = fabs(dn);
+            red[0] = up > red[0] ? up : red[0];
+            red[1] = mag > red[1] ? mag : red[1];
+            if (up != up || mag != mag) red[0] = INFINITY;
+        } else {
+            out[c] = dn;
+        }
+    }
+    TEDD_HD void operator()(int li, int j) const {
+        double red[2] = {0.0, 0.0};
+        (*this)(li, j, red);
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// Newton residuals  2 v1 - dt F_v(S'' , t1) - Y_v  on the full array, where S'' is the lagged
+// state with the already-updated unknowns substituted (prob1base.py:3041-3043, 3076-3078,
+// 3111-3113).
+template <int VAR, int CASE, int REACT>
+struct ResidualFn {
+    GridDev g;
+    ModelC m;
+    MmsTabs tb;
+    ForcingSrc f1;
+    const double *cp1, *cs1, *T1, *cl1, *cd1, *Y;
+    double* out;
+    double dt;
+    TEDD_HD void operator()(int li, int j) const {
+        const size_t c = at(g, li, j);
+        const bool in = is_interior(g, li, j);
+        double fv;
+        if (CASE == CASE_STREAM) {
+            fv = f1.f[VAR][c];
+        } else {
+            const MmsPt p = mms_node<CASE>(m, f1.tm, tb, li, j);
+            fv = (VAR == VAR_T) ? mms_fT(m, p) : (VAR == VAR_CL) ? mms_fcl(m, p) : mms_fcd<REACT>(m, p);
+        }
+        double F = fv;
+        const double* u = (VAR == VAR_T) ? T1 : (VAR == VAR_CL) ? cl1 : cd1;
+        if (in) {
+            const Geo ge = geo_at(g, li, j);
+            if (VAR == VAR_T) {
+                F += rhs_T(m, ge, load5(T1, g, li, j), cp1[c]);
+            } else if (VAR == VAR_CL) {
+                const St5 cp = load5(cp1, g, li, j);
+                F += rhs_cl(m, ge, faces_Dl(m, cp), load5(T1, g, li, j), load5(cl1, g, li, j), cp.c);
+            } else {
+                const St5 cp = load5(cp1, g, li, j), T = load5(T1, g, li, j), cd = load5(cd1, g, li, j);
+                F += rhs_cd_diffusion(ge, faces_Dd(m, cp, T), cd) + reaction<REACT>(m, cl1[c], cd.c, cs1[c]);
+            }
+        }
+        out[c] = 2.0 * u[c] - dt * F - Y[c];
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// Correctors.  cp: closed-form trapezoid (prob1base.py:2967-2996).  cs for CsTriple:
+// closed-form trapezoid (3190-3219).  cs for RegHCsTriple: scalar Newton per node
+// (3647-3702); the per-node inputs y, a are prepared by cs_newton_inputs and iterated by
+// cs_newton_step; the kernel/loop around them reproduces the reference's global early exit.
+template <int CASE, int REACT>
+struct CorrectIn {
+    GridDev g;
+    ModelC m;
+    MmsTabs tb;
+    ForcingSrc f0, f1;
+    Fields5 S0;
+    const double *T1, *cl1, *cd1;
+    const double *fcp_t0, *fcp_t1;  // cached cell averages (closed-form cases); may be null
+    double dt;
+};
+
+template <int CASE, int REACT>
+TEDD_HD double corrector_cp(const CorrectIn<CASE, REACT>& a, int li, int j) {
+    const size_t c = at(a.g, li, j);
+    if (!is_interior(a.g, li, j)) return 0.0;
+    double s0, s1;
+    if (CASE == CASE_STREAM) {
+        s0 = a.f0.f[0][c];
+        s1 = a.f1.f[0][c];
+    } else {
+        s0 = a.fcp_t0 ? a.fcp_t0[c] : mms_fcp_cellavg<CASE>(a.m, a.f0.tm, a.tb, li, j);
+        s1 = a.fcp_t1 ? a.fcp_t1[c] : mms_fcp_cellavg<CASE>(a.m, a.f1.tm, a.tb, li, j);
+    }
+    const ModelC& m = a.m;
+    const double h = a.dt / 2;
+    const double al0 = -m.K2 * a.S0.v[VAR_T][c] - m.K1 * (a.S0.v[VAR_CL][c] + 1.0);
+    const double al1 = -m.K2 * a.T1[c] - m.K1 * (a.cl1[c] + 1.0);
+    const double num = (1.0 + h * al0) * a.S0.v[VAR_CP][c] + h * (s0 + s1);
+    return num / (1.0 - h * al1);
+}
+
+template <int CASE, int REACT>
+TEDD_HD void forcing_fcs_pair(const CorrectIn<CASE, REACT>& a, int li, int j, double& s0, double& s1) {
+    const size_t c = at(a.g, li, j);
+    if (CASE == CASE_STREAM) {
+        s0 = a.f0.f[4][c];
+        s1 = a.f1.f[4][c];
+    } else {
+        s0 = mms_fcs<REACT>(a.m, mms_node<CASE>(a.m, a.f0.tm, a.tb, li, j));
+        s1 = mms_fcs<REACT>(a.m, mms_node<CASE>(a.m, a.f1.tm, a.tb, li, j));
+    }
+}
+
+template <int CASE, int REACT>
+TEDD_HD double corrector_cs_closed_form(const CorrectIn<CASE, REACT>& a, int li, int j) {
+    const size_t c = at(a.g, li, j);
+    if (!is_interior(a.g, li, j)) return 0.0;
+    double s0, s1;
+    forcing_fcs_pair(a, li, j, s0, s1);
+    const ModelC& m = a.m;
+    const double h = a.dt / 2;
+    const double b0 = -m.Kd * (m.Sd - a.S0.v[VAR_CD][c]) * (1.0 + a.S0.v[VAR_CL][c]);
+    const double b1 = -m.Kd * (m.Sd - a.cd1[c]) * (1.0 + a.cl1[c]);
+    const double num = (1.0 + h * b0) * a.S0.v[VAR_CS][c] + h * (s0 + s1);
+    return num / (1.0 - h * b1);
+}
+
+// y and a of  2x + (2x - y) e^{-eta x} = y - a   (all nodes, boundary included)
+template <int CASE, int REACT>
+TEDD_HD void cs_newton_inputs(const CorrectIn<CASE, REACT>& a, int li, int j, double& y, double& av, double& x0) {
+    const size_t c = at(a.g, li, j);
+    double s0, s1;
+    forcing_fcs_pair(a, li, j, s0, s1);
+    const ModelC& m = a.m;
+    const double cs0 = a.S0.v[VAR_CS][c], cl0 = a.S0.v[VAR_CL][c], cd0 = a.S0.v[VAR_CD][c];
+    y = 2.0 * cs0 - a.dt * m.Kd * (m.Sd - cd0) * (cl0 + 1.0) * heaviside_reg(cs0, m.eta) + a.dt * (s0 + s1);
+    av = a.dt * m.Kd * (m.Sd - a.cd1[c]) * (a.cl1[c] + 1.0);
+    x0 = cs0;
+}
+// one Newton update; returns dx
+TEDD_HD double cs_newton_step(double x, double y, double av, double eta) {
+    const double ex = exp(-eta * x);
+    const double f = 2.0 * x + (2.0 * x - y) * ex - y + av;
+    const double J = 2.0 + 2.0 * ex - eta * (2.0 * x - y) * ex;
+    return -f / J;
+}
+
+// ------------------------------------------------------------------------------------
+// Exact solution at the nodes (closed-form cases only).
+template <int CASE>
+struct ExactFn {
+    GridDev g;
+    ModelC m;
+    MmsTabs tb;
+    MmsTime tm;
+    Out5 out;
+    TEDD_HD void operator()(int li, int j) const {
+        const MmsPt p = mms_node<CASE>(m, tm, tb, li, j);
+        const size_t c = at(g, li, j);
+        out.v[0][c] = p.cp;
+        out.v[1][c] = p.T;
+        out.v[2][c] = p.cl;
+        out.v[3][c] = p.cd;
+        out.v[4][c] = p.cs;
+    }
+};
+
+// The five forcing arrays at one time (parity hook for the MMS source terms).
+template <int CASE, int REACT>
+struct ForcingFn {
+    GridDev g;
+    ModelC m;
+    MmsTabs tb;
+    ForcingSrc f0;
+    Out5 out;
+    TEDD_HD void operator()(int li, int j) const {
+        const Forcing5 f = node_forcing<CASE, REACT>(m, tb, f0, g, li, j, is_interior(g, li, j), true);
+        const size_t c = at(g, li, j);
+        out.v[0][c] = f.fcp;
+        out.v[1][c] = f.fT;
+        out.v[2][c] = f.fcl;
+        out.v[3][c] = f.fcd;
+        out.v[4][c] = f.fcs;
+    }
+};
+
+// Jacobian stencil coefficient arrays (parity hook).  op: 0 dFT/dT, 1 dFcl/dT, 2 dFcl/dcl,
+// 3 dFcd/dT, 4 dFcd/dcl, 5 dFcd/dcd.  out = coefficient at (0,0),(1,0),(-1,0),(0,1),(0,-1).
+template <int REACT>
+struct JacobianFn {
+    GridDev g;
+    ModelC m;
+    Fields5 S;
+    Out5 out;
+    int op;
+    TEDD_HD void operator()(int li, int j) const {
+        const size_t c = at(g, li, j);
+        Coef5 r{0, 0, 0, 0, 0};
+        if (is_interior(g, li, j)) {
+            const Geo ge = geo_at(g, li, j);
+            const int i = g.i0 + li;
+            const double w_ok = (i > 1) ? 1.0 : 0.0, e_ok = (i < g.N - 1) ? 1.0 : 0.0;
+            const St5 cp = load5(S.v[VAR_CP], g, li, j), T = load5(S.v[VAR_T], g, li, j);
+            const St5 cl = load5(S.v[VAR_CL], g, li, j), cd = load5(S.v[VAR_CD], g, li, j);
+            const double cs = S.v[VAR_CS][c];
+            switch (op) {
+                case 0: r = jac_T_FT(m, ge, cp.c); break;
+                case 1: r = jac_T_Fcl(m, ge, cl, w_ok, e_ok); break;
+                case 2: r = jac_cl_Fcl(m, ge, faces_Dl(m, cp), T, cp.c, w_ok, e_ok); break;
+                case 3: r = jac_T_Fcd(ge, faces_dDd_dT(m, cp, T), cd); break;
+                case 4: r.c = jac_cl_Fcd_diag<REACT>(m, cd.c, cs); break;
+                default: r = jac_cd_Fcd<REACT>(m, ge, faces_Dd(m, cp, T), cl.c, cs); break;
+            }
+        }
+        out.v[0][c] = r.c;
+        out.v[1][c] = r.e;
+        out.v[2][c] = r.w;
+        out.v[3][c] = r.n;
+        out.v[4][c] = r.s;
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// Error norms against the exact solution (mms_trial_utils.py:81-110 with prob1base.py:387-433):
+// red[v] += e_v^2 hm_i km_j on interior nodes (v = cp,T,cl,cd,cs);
+// red[5+q] += (D-x e)^2 h_i km_j [i>=1, 1<=j<=M-1] + (D-y e)^2 hm_i k_j [1<=i<=N-1, j>=1],
+// q = 0,1,2 for T, cl, cd.  Only rows the caller owns are visited.
+template <int CASE>
+struct ErrNormFn {
+    GridDev g;
+    ModelC m;
+    MmsTabs tb;
+    MmsTime tm;
+    Fields5 S;
+    const double* ex[5];  // exact fields when CASE_STREAM (uploaded by the caller)
+    static constexpr int NR = 8;
+    TEDD_HD void exact5(int li, int j, double* e) const {
+        if (CASE == CASE_STREAM) {
+            const size_t c = at(g, li, j);
+            for (int v = 0; v < 5; ++v) e[v] = ex[v][c];
+        } else {
+            const MmsPt p = mms_node<CASE>(m, tm, tb, li, j);
+            e[0] = p.cp; e[1] = p.T; e[2] = p.cl; e[3] = p.cd; e[4] = p.cs;
+        }
+    }
+    TEDD_HD void operator()(int li, int j, double* red) const {
+        const int i = g.i0 + li;
+        const size_t c = at(g, li, j);
+        double ec[5];
+        exact5(li, j, ec);
+        double err[5];
+        for (int v = 0; v < 5; ++v) err[v] = S.v[v][c] - ec[v];
+        const bool in = is_interior(g, li, j);
+        if (in) {
+            const double w = g.hm[li] * g.km[j];
+            for (int v = 0; v < 5; ++v) red[v] += err[v] * err[v] * w;
+        }
+        const bool xterm = (i >= 1 && j >= 1 && j <= g.M - 1);
+        const bool yterm = (i >= 1 && i <= g.N - 1 && j >= 1);
+        if (xterm) {
+            double ew[5];
+            exact5(li - 1, j, ew);
+            const double wgt = g.h[li] * g.km[j];
+            for (int q = 0; q < 3; ++q) {
+                const int v = q + 1;
+                const double dnum = (S.v[v][c] - S.v[v][c - g.ld]) * g.rh[li];
+                const double dex = (ec[v] - ew[v]) * g.rh[li];
+                const double d = dnum - dex;
+                red[5 + q] += d * d * wgt;
+            }
+        }
+        if (yterm) {
+            double es[5];
+            exact5(li, j - 1, es);
+            const double wgt = g.hm[li] * g.k[j];
+            for (int q = 0; q < 3; ++q) {
+                const int v = q + 1;
+                const double dnum = (S.v[v][c] - S.v[v][c - 1]) * g.rk[j];
+                const double dex = (ec[v] - es[v]) * g.rk[j];
+                const double d = dnum - dex;
+                red[5 + q] += d * d * wgt;
+            }
+        }
+    }
+};
+
+}  // namespace tedd

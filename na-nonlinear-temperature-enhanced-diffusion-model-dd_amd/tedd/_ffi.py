@@ -1,0 +1,307 @@
+"""ctypes binding of the C ABI declared in include/tedd.h (libtedd_hip.so).
+
+The library is loaded from `<package root>/lib/libtedd_hip.so`.  There is no CPU fallback:
+if the HIP library is missing or cannot be loaded, every entry into the device path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEFAULT_LIBRARY = os.path.join(_PKG_ROOT, "lib", "libtedd_hip.so")
+
+CONST_NAMES = ("R0", "Ea", "K1", "K2", "K3", "K4", "DT", "Dl_max", "phi_l", "gamma_T",
+               "Kd", "Sd", "Dd_max", "phi_d", "phi_T", "r_sp", "T_ref")
+
+MMS_STREAM, MMS_POL, MMS_EXPSIN, MMS_PEAKS, MMS_NFS = -1, 0, 1, 2, 3
+REACT_CSTRIPLE, REACT_REGHCSTRIPLE = 0, 1
+
+_dptr = C.POINTER(C.c_double)
+_i32ptr = C.POINTER(C.c_int32)
+
+
+class TeddConfig(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("M", C.c_int32),
+        ("row_lo", C.c_int32), ("row_hi", C.c_int32),
+        ("ghost", C.c_int32), ("model_kind", C.c_int32),
+        ("reaction_kind", C.c_int32), ("mms_case", C.c_int32),
+        ("device", C.c_int32), ("reserved", C.c_int32),
+        ("eta", C.c_double),
+        ("consts", C.c_double * 17),
+        ("mms_params", C.c_double * 8),
+    ]
+
+
+class TeddStepStats(C.Structure):
+    _fields_ = [
+        ("sweeps", C.c_int32 * 3), ("cs_iterations", C.c_int32),
+        ("last_update", C.c_double * 3), ("increment", C.c_double * 3),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/tedd.h declares
+PROTOTYPES = {
+    "tedd_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(TeddConfig), _dptr, _dptr]),
+    "tedd_destroy": (None, [C.c_void_p]),
+    "tedd_last_error": (C.c_char_p, [C.c_void_p]),
+    "tedd_set_model": (C.c_int, [C.c_void_p, _dptr, C.c_int32, C.c_double, _dptr]),
+    "tedd_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tedd_sync": (C.c_int, [C.c_void_p]),
+    "tedd_local_rows": (C.c_int32, [C.c_void_p]),
+    "tedd_row_offset": (C.c_int32, [C.c_void_p]),
+    "tedd_pitch": (C.c_int32, [C.c_void_p]),
+    "tedd_set_state": (C.c_int, [C.c_void_p] + [_dptr] * 5),
+    "tedd_get_state": (C.c_int, [C.c_void_p] + [_dptr] * 5),
+    "tedd_state_device_ptrs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "tedd_ghosts_refreshed": (C.c_int, [C.c_void_p]),
+    "tedd_set_state_exact": (C.c_int, [C.c_void_p, C.c_double]),
+    "tedd_set_forcing": (C.c_int, [C.c_void_p, C.c_int32] + [_dptr] * 5),
+    "tedd_step_pc": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_double, _i32ptr, C.c_double, C.c_int32]),
+    "tedd_step_feuler": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "tedd_advance": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_int32, C.c_int32, C.c_double, _i32ptr, C.c_double, C.c_int32, _dptr]),
+    "tedd_get_residuals": (C.c_int, [C.c_void_p] + [_dptr] * 3),
+    "tedd_eval_field": (C.c_int, [C.c_void_p, C.c_double] + [_dptr] * 5),
+    "tedd_eval_exact": (C.c_int, [C.c_void_p, C.c_double] + [_dptr] * 5),
+    "tedd_eval_forcing": (C.c_int, [C.c_void_p, C.c_double] + [_dptr] * 5),
+    "tedd_eval_jacobian": (C.c_int, [C.c_void_p, C.c_int32] + [_dptr] * 5),
+    "tedd_error_norms": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(_dptr), _dptr]),
+    "tedd_get_stats": (C.c_int, [C.c_void_p, C.POINTER(TeddStepStats)]),
+    "tedd_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "tedd_profile_get": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), _dptr]),
+}
+
+_lock = threading.Lock()
+_lib = None
+_lib_path = DEFAULT_LIBRARY
+
+
+def bind(lib):
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def use_library(path):
+    """Load the C-ABI library from an explicit path (tests use this for the host twin)."""
+    global _lib, _lib_path
+    with _lock:
+        _lib = bind(C.CDLL(path))
+        _lib_path = path
+    return _lib
+
+
+def library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_lib_path):
+            raise RuntimeError(
+                f"tedd: the HIP library {_lib_path} is missing; build it with "
+                "`python __graft_entry__.py build` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        use_library(_lib_path)
+    return _lib
+
+
+def library_path():
+    return _lib_path
+
+
+def _raise(rc, msg):
+    msg = msg or f"tedd error {rc}"
+    if rc == -1:
+        raise ValueError(msg)
+    if rc == -2:
+        raise AssertionError(msg)
+    raise RuntimeError(msg)
+
+
+def _arr(a):
+    return a.ctypes.data_as(_dptr) if a is not None else None
+
+
+class Context:
+    """One device context (one slab of the mesh).  Thin, allocation-explicit wrapper."""
+
+    def __init__(self, x, y, consts, *, model_kind=2, reaction_kind=REACT_REGHCSTRIPLE, eta=0.0,
+                 mms_case=MMS_STREAM, mms_params=(), row_lo=0, row_hi=None, ghost=0, device=-1):
+        self._lib = library()
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        self.N, self.M = len(x) - 1, len(y) - 1
+        cfg = TeddConfig()
+        cfg.N, cfg.M = self.N, self.M
+        cfg.row_lo = row_lo
+        cfg.row_hi = self.N + 1 if row_hi is None else row_hi
+        cfg.ghost = ghost
+        cfg.model_kind = model_kind
+        cfg.reaction_kind = reaction_kind
+        cfg.mms_case = mms_case
+        cfg.device = device
+        cfg.eta = float(eta)
+        for k, v in enumerate(consts):
+            cfg.consts[k] = float(v)
+        params = list(mms_params) + [0.0] * (8 - len(mms_params))
+        for k in range(8):
+            cfg.mms_params[k] = float(params[k])
+        h = C.c_void_p()
+        rc = self._lib.tedd_create(C.byref(h), C.byref(cfg), _arr(x), _arr(y))
+        if rc != 0:
+            _raise(rc, (self._lib.tedd_last_error(None) or b"").decode())
+        self._h = h
+        self.mms_case = mms_case
+        self.reaction_kind = reaction_kind
+        self.nrows = int(self._lib.tedd_local_rows(h))
+        self.row_offset = int(self._lib.tedd_row_offset(h))
+        self.pitch = int(self._lib.tedd_pitch(h))
+        self.shape = (self.nrows, self.M + 1)
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.tedd_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            _raise(rc, (self._lib.tedd_last_error(self._h) or b"").decode())
+        return rc
+
+    def _in(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.shape != self.shape:
+            raise AssertionError(f"array shape {a.shape} != local mesh shape {self.shape}")
+        return a
+
+    def _out(self, n):
+        return [np.empty(self.shape, dtype=np.float64) for _ in range(n)]
+
+    # -- configuration
+    def set_model(self, consts, model_kind, eta, mms_params=()):
+        c = (C.c_double * 17)(*[float(v) for v in consts])
+        params = list(mms_params) + [0.0] * (8 - len(mms_params))
+        p = (C.c_double * 8)(*[float(v) for v in params])
+        self._check(self._lib.tedd_set_model(self._h, c, model_kind, float(eta), p))
+
+    def set_stream(self, stream_handle):
+        self._check(self._lib.tedd_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def sync(self):
+        self._check(self._lib.tedd_sync(self._h))
+
+    # -- state
+    def set_state(self, cp, T, cl, cd, cs):
+        arrs = [self._in(a) for a in (cp, T, cl, cd, cs)]
+        self._check(self._lib.tedd_set_state(self._h, *[_arr(a) for a in arrs]))
+
+    def get_state(self):
+        out = self._out(5)
+        self._check(self._lib.tedd_get_state(self._h, *[_arr(a) for a in out]))
+        return out
+
+    def set_state_exact(self, t):
+        self._check(self._lib.tedd_set_state_exact(self._h, float(t)))
+
+    def state_device_ptrs(self):
+        p = (C.c_void_p * 5)()
+        self._check(self._lib.tedd_state_device_ptrs(self._h, p))
+        return [int(v) for v in p]
+
+    def ghosts_refreshed(self):
+        self._check(self._lib.tedd_ghosts_refreshed(self._h))
+
+    def set_forcing(self, which, fcp, fT, fcl, fcd, fcs):
+        arrs = [self._in(a) for a in (fcp, fT, fcl, fcd, fcs)]
+        self._check(self._lib.tedd_set_forcing(self._h, which, *[_arr(a) for a in arrs]))
+
+    # -- stepping
+    @staticmethod
+    def _sweeps(sweeps):
+        if sweeps is None:
+            return None
+        return (C.c_int32 * 3)(*[int(s) for s in sweeps])
+
+    def step_pc(self, t0, dt, *, num_pc_steps=1, num_newton_steps=1, cs_newton_iterations=5,
+                cs_consec_xs_rtol=1e-6, jacobi_sweeps=None, jacobi_tol=1e-13, jacobi_max=100000):
+        self._check(self._lib.tedd_step_pc(self._h, float(t0), float(dt), num_pc_steps, num_newton_steps,
+                                           cs_newton_iterations, float(cs_consec_xs_rtol),
+                                           self._sweeps(jacobi_sweeps), float(jacobi_tol), jacobi_max))
+
+    def step_feuler(self, t0, dt):
+        self._check(self._lib.tedd_step_feuler(self._h, float(t0), float(dt)))
+
+    def advance(self, t0, dt, nsteps, *, integrator=1, num_pc_steps=1, num_newton_steps=1,
+                cs_newton_iterations=5, cs_consec_xs_rtol=1e-6, jacobi_sweeps=None, jacobi_tol=1e-13,
+                jacobi_max=100000, want_errors=True):
+        series = np.empty((nsteps + 1, 8), dtype=np.float64) if want_errors else None
+        self._check(self._lib.tedd_advance(self._h, float(t0), float(dt), nsteps, integrator, num_pc_steps,
+                                           num_newton_steps, cs_newton_iterations, float(cs_consec_xs_rtol),
+                                           self._sweeps(jacobi_sweeps), float(jacobi_tol), jacobi_max,
+                                           _arr(series)))
+        return series
+
+    def get_residuals(self):
+        out = self._out(3)
+        self._check(self._lib.tedd_get_residuals(self._h, *[_arr(a) for a in out]))
+        return out
+
+    def get_stats(self):
+        s = TeddStepStats()
+        self._check(self._lib.tedd_get_stats(self._h, C.byref(s)))
+        return {"sweeps": list(s.sweeps), "cs_iterations": int(s.cs_iterations),
+                "last_update": list(s.last_update), "increment": list(s.increment)}
+
+    # -- parity hooks
+    def eval_field(self, t):
+        out = self._out(5)
+        self._check(self._lib.tedd_eval_field(self._h, float(t), *[_arr(a) for a in out]))
+        return out
+
+    def eval_exact(self, t):
+        out = self._out(5)
+        self._check(self._lib.tedd_eval_exact(self._h, float(t), *[_arr(a) for a in out]))
+        return out
+
+    def eval_forcing(self, t):
+        out = self._out(5)
+        self._check(self._lib.tedd_eval_forcing(self._h, float(t), *[_arr(a) for a in out]))
+        return out
+
+    def eval_jacobian(self, op):
+        out = self._out(5)
+        self._check(self._lib.tedd_eval_jacobian(self._h, int(op), *[_arr(a) for a in out]))
+        return out
+
+    def error_norms(self, t, exact=None):
+        out = np.empty(8, dtype=np.float64)
+        if exact is not None:
+            arrs = [self._in(a) for a in exact]
+            ptrs = (_dptr * 5)(*[_arr(a) for a in arrs])
+            self._check(self._lib.tedd_error_norms(self._h, float(t), ptrs, _arr(out)))
+        else:
+            self._check(self._lib.tedd_error_norms(self._h, float(t), None, _arr(out)))
+        return out
+
+    # -- timing record
+    def profile_enable(self, on=True):
+        self._check(self._lib.tedd_profile_enable(self._h, 1 if on else 0))
+
+    def profile_get(self):
+        cap = 32
+        names = (C.c_char_p * cap)()
+        n = (C.c_int64 * cap)()
+        ms = (C.c_double * cap)()
+        k = self._check(self._lib.tedd_profile_get(self._h, cap, names, n, ms))
+        return {names[i].decode(): {"launches": int(n[i]), "total_ms": float(ms[i])} for i in range(k)}

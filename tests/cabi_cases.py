@@ -1,0 +1,125 @@
+"""Shared drivers for the C-ABI parity tests: they run one golden fixture through a C-ABI
+library (the HIP library on a GPU box, or the host twin on CPU) and return error measures."""
+import os
+
+import numpy as np
+
+from tedd import _ffi
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+VARS = ("cp", "T", "cl", "cd", "cs")
+CASE_ID = {"pol": _ffi.MMS_POL, "expsin": _ffi.MMS_EXPSIN, "peaks_fast1e1": _ffi.MMS_PEAKS,
+           "nfs_h2_h3": _ffi.MMS_NFS}
+CASE_PARAMS = {"pol": (), "expsin": (), "peaks_fast1e1": (1.0, 10.0),
+               "nfs_h2_h3": (2.1, 3.1, 3.1, 3.1, 2.1, 1.0 / np.pi)}
+JAC_OPS = ["delT_ab_FT_ij", "delT_ab_Fcl_ij", "delcl_ab_Fcl_ij", "delT_ab_Fcd_ij", "delcl_ab_Fcd_ij",
+           "delcd_ab_Fcd_ij"]
+
+_cache = {}
+
+
+def load(name):
+    if name not in _cache:
+        _cache[name] = np.load(os.path.join(GOLDEN, name))
+    return _cache[name]
+
+
+def tags(name, marker):
+    z = load(name)
+    return sorted({k[: -len(marker)] for k in z.files if k.endswith(marker)})
+
+
+def make_ctx(z, tag, react, mms_case, mms_params=()):
+    return _ffi.Context(z[f"{tag}/x"], z[f"{tag}/y"], z[f"{tag}/consts"],
+                        model_kind=int(z[f"{tag}/model_kind"]), reaction_kind=react,
+                        eta=float(z[f"{tag}/eta"]), mms_case=mms_case, mms_params=mms_params)
+
+
+def relerr(a, b, scale=None):
+    s = np.max(np.abs(b)) if scale is None else scale
+    d = np.max(np.abs(np.asarray(a) - np.asarray(b)))
+    return d / s if s > 0 else d
+
+
+def check_ops(tag):
+    """F* and the six Jacobian stencils on a random state with zero forcing. Returns max error."""
+    z = load("golden_ops.npz")
+    worst = 0.0
+    for rname, rk in (("reg", _ffi.REACT_REGHCSTRIPLE), ("cs3", _ffi.REACT_CSTRIPLE)):
+        ctx = make_ctx(z, tag, rk, _ffi.MMS_STREAM)
+        S = [z[f"{tag}/{v}"] for v in VARS]
+        ctx.set_state(*S)
+        zero = np.zeros_like(S[0])
+        ctx.set_forcing(0, zero, zero, zero, zero, zero)
+        F = ctx.eval_field(0.3)
+        for v, a in zip(VARS, F):
+            worst = max(worst, relerr(a, z[f"{tag}/{rname}/F{v}"]))
+        for op, name in enumerate(JAC_OPS):
+            J = ctx.eval_jacobian(op)
+            g = z[f"{tag}/{rname}/{name}"]
+            sc = np.max(np.abs(g))
+            for n in range(5):
+                worst = max(worst, relerr(J[n], g[n], sc))
+        ctx.close()
+    return worst
+
+
+def check_mms(tag):
+    """Exact solution and the five forcing arrays of a closed-form case at two times."""
+    z = load("golden_mms.npz")
+    cname = tag.split("/")[0]
+    worst_exact, worst_forcing = 0.0, 0.0
+    for rname, rk in (("reg", _ffi.REACT_REGHCSTRIPLE), ("cs3", _ffi.REACT_CSTRIPLE)):
+        ctx = make_ctx(z, tag, rk, CASE_ID[cname], CASE_PARAMS[cname])
+        for it in (0, 1):
+            tt = f"{tag}/t{it}"
+            t = float(z[f"{tt}/t"])
+            for v, a in zip(VARS, ctx.eval_exact(t)):
+                worst_exact = max(worst_exact, relerr(a, z[f"{tt}/{v}"]))
+            fscale = max(1.0, np.max(np.abs(z[f"{tt}/cp"])))
+            for v, a in zip(("fcp", "fT", "fcl", "fcd", "fcs"), ctx.eval_forcing(t)):
+                worst_forcing = max(worst_forcing, relerr(a, z[f"{tt}/{rname}/{v}"], fscale))
+        ctx.close()
+    return worst_exact, worst_forcing
+
+
+def run_steps(tag, **overrides):
+    """Integrate a golden step fixture; returns (max state error relative to the field scale,
+    max absolute residual error, stats of the last step)."""
+    z = load("golden_steps.npz")
+    kind = tag.split("/")[0]
+    cname = str(z[f"{tag}/case"]) if f"{tag}/case" in z.files else tag.split("/")[1]
+    rk = _ffi.REACT_REGHCSTRIPLE if kind.endswith("reg") else _ffi.REACT_CSTRIPLE
+    ctx = make_ctx(z, tag, rk, CASE_ID[cname], CASE_PARAMS[cname])
+    ctx.set_state(*[z[f"{tag}/s0/{v}"] for v in VARS])
+    t0, dt = float(z[f"{tag}/t0"]), float(z[f"{tag}/dt"])
+    saved = sorted(int(k.split("/")[-2][1:]) for k in z.files
+                   if k.startswith(tag + "/s") and k.endswith("/cp") and "/s0/" not in k)
+    kw = {}
+    is_pc = kind.startswith("pc")
+    if is_pc:
+        for name in ("num_pc_steps", "num_newton_steps"):
+            if f"{tag}/{name}" in z.files:
+                kw[name] = int(z[f"{tag}/{name}"])
+        if rk == _ffi.REACT_REGHCSTRIPLE:
+            kw["cs_newton_iterations"] = int(z[f"{tag}/num_newton_iterations"])
+            kw["cs_consec_xs_rtol"] = float(z[f"{tag}/consec_xs_rtol"])
+        kw.update(overrides)
+    t, worst, wres = t0, 0.0, 0.0
+    for k in range(1, max(saved) + 1):
+        if is_pc:
+            ctx.step_pc(t, dt, **kw)
+        else:
+            ctx.step_feuler(t, dt)
+        t += dt
+        if k in saved:
+            out = ctx.get_state()
+            scale = max(np.max(np.abs(z[f"{tag}/s{k}/{v}"])) for v in VARS)
+            for v, a in zip(VARS, out):
+                worst = max(worst, np.max(np.abs(a - z[f"{tag}/s{k}/{v}"])) / scale)
+            if is_pc:
+                for v, a in zip(("T", "cl", "cd"), ctx.get_residuals()):
+                    wres = max(wres, np.max(np.abs(a - z[f"{tag}/s{k}/res_{v}"])))
+    stats = ctx.get_stats() if is_pc else {}
+    ctx.close()
+    return worst, wres, stats
