@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: predictor-corrector time steps of the MMSCaseExpSin problem.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (all ranks together): the ExpSin MMS problem on the synthetic 16384 x 16384-cell mesh
+(4096x the cells of the finest convergence-study mesh, N=256), notebook model constants,
+eta = 50, dt = h^1.5, state = exact solution at t = 0 (generated on the device).  With N > 1 the
+mesh rows are split into N slabs (strong scaling, one ghost-row exchange per step over RCCL).
+A "step" is one call of the predictor-corrector integrator (reference
+P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple.step); value = steps / second.
+
+The JSON line also carries
+  roofline      HBM roofline of the kernel family with the largest share of the timed region
+                (algorithmic bytes per launch / average launch duration from HIP events)
+  study_mesh    steps/s on the finest convergence-study mesh (N=256), rank 0 at --gpus 1 only
+  cpu_baseline  the CPU oracle (NumPy/SciPy restatement of the reference, 1 core) timed on the
+                N=256 mesh, rank 0 at --gpus 1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "na-nonlinear-temperature-enhanced-diffusion-model-dd_amd"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (8 TB/s)
+
+NB_A = dict(R0=8.3144621, Ea=1.60217662e-19, K1=1e-3, K2=1e-3, K3=1e-3, K4=1e-3, DT=1e-3,
+            Dl_max=1e-5, phi_l=1e-5, gamma_T=1e-9, Kd=1e-2, Sd=1, Dd_max=1e-6, phi_d=1e-5,
+            phi_T=1.60217662e-19 / 8.3144621, r_sp=5e-2, T_ref=300)
+
+# distinct full-grid arrays read + written per launch of each kernel family (algorithmic traffic,
+# 8 bytes per node per array; halos and 1-D tables ignored)
+ARRAYS_PER_LAUNCH = {
+    "predict": 12,    # reads cp,T,cl,cd,cs + cached cell-averaged fcp(t0); writes Y_T,Y_cl,Y_cd,cp*,cs*,fcp(t1)
+    "rhs_T": 5,       # reads cp*, T, Y_T; writes rhs, delta_1
+    "rhs_cl": 7,      # reads cp*, T, T_new, cl, Y_cl; writes rhs, delta_1
+    "rhs_cd": 10,     # reads cp*, cs*, T, T_new, cl, cl_new, cd, Y_cd; writes rhs, delta_1
+    "jacobi_T": 4,    # reads delta, rhs, cp*; writes delta (final sweep: +T, writes T_new)
+    "jacobi_cl": 5,   # reads delta, rhs, cp*, T; writes delta
+    "jacobi_cd": 7,   # reads delta, rhs, cp*, T, cl, cs*; writes delta
+    "cs_newton": 12,  # reads cp,T,cl,cd,cs, T_new,cl_new,cd_new, fcp(t0), fcp(t1); writes cp_new, cs_new
+}
+
+
+def consts_vec(d):
+    from tedd import _ffi
+    return [float(d[k]) for k in _ffi.CONST_NAMES]
+
+
+def pick_sweeps(N, dt, jacobi_tol):
+    """Sweep counts the library would pick (same contraction bound), needed up-front to size the ghost zone."""
+    q_metric = 4.0 * N * N
+    out = []
+    for D in (NB_A["DT"], NB_A["Dl_max"], NB_A["Dd_max"]):
+        q = dt * D * q_metric
+        rho = q / (2.0 + q)
+        out.append(max(2, int(np.ceil(np.log(jacobi_tol) / np.log(rho)) + 1)))
+    return out
+
+
+def study_mesh_run(N=256, steps=400, warmup=20):
+    from tedd import _ffi
+    x = np.linspace(0, 1, N + 1)
+    ctx = _ffi.Context(x, x, consts_vec(NB_A), model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+                       mms_case=_ffi.MMS_EXPSIN)
+    dt = (1.0 / N) ** 1.5
+    ctx.set_state_exact(0.0)
+    ctx.advance(0.0, dt, warmup, want_errors=False)
+    ctx.sync()
+    t0 = time.perf_counter()
+    ctx.advance(warmup * dt, dt, steps, want_errors=False)
+    ctx.sync()
+    el = time.perf_counter() - t0
+    stats = ctx.get_stats()
+    ctx.close()
+    return {"workload": f"ExpSin N={N}, dt=h^1.5, eta=50, device-resident steps", "steps": steps,
+            "steps_per_s": steps / el, "ms_per_step": 1e3 * el / steps, "jacobi_sweeps": stats["sweeps"]}
+
+
+def cpu_baseline_run(N=256, steps=4):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import tedd_oracle as orc
+    model = orc.Model(NB_A, 2)
+    pb = orc.Problem(orc.Mesh.uniform(N), model, orc.make_case("expsin", model), "reg", 50.0)
+    dt = (1.0 / N) ** 1.5
+    S = pb.exact_state(0.0)
+    t = 0.0
+    t0 = time.perf_counter()
+    f_prev = pb.forcing(t)
+    for _ in range(steps):
+        f_next = pb.forcing(t + dt)
+        S, _ = orc.step_pc(pb, S, t, dt, forcing0=f_prev, forcing1=f_next, want_residual=False)
+        f_prev = f_next
+        t += dt
+    el = time.perf_counter() - t0
+    return {"value": steps / el, "unit": "time-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} predictor-corrector steps of ExpSin on the N={N} mesh (finest convergence-study "
+                      f"mesh) with the NumPy/SciPy oracle (spsolve), forcing evaluated once per time level"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mesh", type=int, default=16384, help="N of the (N+1)^2-node synthetic mesh")
+    ap.add_argument("--jacobi-tol", type=float, default=1e-13)
+    ap.add_argument("--no-extras", action="store_true", help="skip the N=256 study-mesh and CPU-baseline legs")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tedd import _ffi
+    from tedd.distributed import SlabStepper, partition_rows
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    N = args.mesh
+    dt = (1.0 / N) ** 1.5
+    sweeps = pick_sweeps(N, dt, args.jacobi_tol)
+    ghost = sum(sweeps) + 3
+    slab = partition_rows(N + 1, world, rank, ghost)
+    x = np.linspace(0, 1, N + 1)
+    ctx = _ffi.Context(x, x, consts_vec(NB_A), model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+                       mms_case=_ffi.MMS_EXPSIN, row_lo=slab.row_lo, row_hi=slab.row_hi, ghost=slab.ghost,
+                       device=local_rank)
+    stepper = SlabStepper(ctx, slab, device)
+    ctx.set_state_exact(0.0)
+    kw = dict(jacobi_sweeps=sweeps, jacobi_tol=args.jacobi_tol)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    t = 0.0
+    for _ in range(args.warmup):
+        stepper.step_pc(t, dt, **kw)
+        t += dt
+    ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stepper.step_pc(t, dt, **kw)
+        t += dt
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+    stats = ctx.get_stats()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # sanity: the run must still track the exact solution
+    norms = ctx.error_norms(t)
+    if world > 1:
+        tn = torch.tensor(norms, dtype=torch.float64, device=device)
+        dist.all_reduce(tn)
+        norms = tn.cpu().numpy()
+    err_H = float(np.sqrt(np.sum(norms[:5])))
+
+    n_nodes_local = (slab.row_hi - slab.row_lo) * (N + 1)
+    fam = max(prof, key=lambda k: prof[k]["total_ms"]) if prof else None
+    roofline = None
+    if fam is not None:
+        per_launch_ms = prof[fam]["total_ms"] / prof[fam]["launches"]
+        bytes_per_launch = 8.0 * n_nodes_local * ARRAYS_PER_LAUNCH.get(fam, 0)
+        achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": fam, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "arrays_per_launch": ARRAYS_PER_LAUNCH.get(fam, 0), "avg_launch_ms": per_launch_ms,
+                    "launches": prof[fam]["launches"], "nodes_per_launch": n_nodes_local}
+    kernels = {k: {"launches": v["launches"], "avg_ms": v["total_ms"] / v["launches"],
+                   "share": v["total_ms"] / (1e3 * elapsed),
+                   "GBps": 8.0 * n_nodes_local * ARRAYS_PER_LAUNCH.get(k, 0) / (v["total_ms"] / v["launches"] * 1e-3) / 1e9}
+               for k, v in prof.items()}
+    arrays_step = (ARRAYS_PER_LAUNCH["predict"] + ARRAYS_PER_LAUNCH["rhs_T"] + ARRAYS_PER_LAUNCH["rhs_cl"]
+                   + ARRAYS_PER_LAUNCH["rhs_cd"] + ARRAYS_PER_LAUNCH["cs_newton"]
+                   + (sweeps[0] - 1) * ARRAYS_PER_LAUNCH["jacobi_T"] + (sweeps[1] - 1) * ARRAYS_PER_LAUNCH["jacobi_cl"]
+                   + (sweeps[2] - 1) * ARRAYS_PER_LAUNCH["jacobi_cd"])
+    step_gbs = 8.0 * (N + 1) * (N + 1) * arrays_step * args.steps / elapsed / 1e9
+
+    out = {
+        "metric": "time-steps/sec, MMSCaseExpSin predictor-corrector (reghcstriple), synthetic 4096x mesh",
+        "value": args.steps / elapsed, "unit": "time-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"MMSCaseExpSin reghcstriple, {N}x{N}-cell mesh ({(N + 1) ** 2} nodes), dt=h^1.5, "
+                               f"eta=50, notebook model constants, 1 PC x 1 Newton step, 5 cs-Newton iterations",
+                   "mesh_N": N, "jacobi_sweeps": sweeps, "jacobi_tol": args.jacobi_tol,
+                   "parallelism": f"row slabs x{world}, ghost={slab.ghost}", "error_H_after_run": err_H},
+        "roofline": roofline,
+        "step_hbm": {"algorithmic_arrays_per_step": arrays_step, "achieved_GBps_all_gpus": step_gbs,
+                     "frac_of_peak": step_gbs / (HBM_PEAK_GBS * world)},
+        "kernels": kernels,
+        "jacobi_last_update": stats["last_update"], "jacobi_increment": stats["increment"],
+    }
+    ctx.close()
+    if rank == 0 and world == 1 and not args.no_extras:
+        sm = study_mesh_run()
+        cb = cpu_baseline_run()
+        sm["speedup_vs_cpu_baseline"] = sm["steps_per_s"] / cb["value"]
+        out["study_mesh"] = sm
+        out["cpu_baseline"] = cb
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
