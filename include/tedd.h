@@ -127,6 +127,10 @@ int tedd_get_residuals(tedd_ctx* ctx, double* rT, double* rcl, double* rcd);
 int tedd_eval_field(tedd_ctx* ctx, double t, double* Fcp, double* FT, double* Fcl, double* Fcd, double* Fcs);
 /* Exact MMS solution at the nodes (closed-form cases). */
 int tedd_eval_exact(tedd_ctx* ctx, double t, double* cp, double* T, double* cl, double* cd, double* cs);
+/* Derivatives of the exact MMS solution at the nodes (MMSCaseBase.dt_*, dx_*, dy_*, lap_*,
+ * src/prob1base.py:736-798): what 0 value, 1 d/dt, 2 d/dx, 3 d/dy, 4 Laplacian.  Entries the forcing
+ * terms never use (Laplacian of cp, space derivatives of cs) come back as NaN. */
+int tedd_eval_mms(tedd_ctx* ctx, double t, int32_t what, double* cp, double* T, double* cl, double* cd, double* cs);
 /* The five forcing arrays at time t (closed-form cases). */
 int tedd_eval_forcing(tedd_ctx* ctx, double t, double* fcp, double* fT, double* fcl, double* fcd, double* fcs);
 /* Jacobian stencil coefficients at the current state: op 0 dFT/dT, 1 dFcl/dT, 2 dFcl/dcl, 3 dFcd/dT,

@@ -166,6 +166,12 @@ int tedd_eval_exact(tedd_ctx* ctx, double t, double* cp, double* T, double* cl, 
         C.eval_exact(t, h);
     });
 }
+int tedd_eval_mms(tedd_ctx* ctx, double t, int32_t what, double* cp, double* T, double* cl, double* cd, double* cs) {
+    return guarded(ctx, [&](auto& C) {
+        double* h[5] = {cp, T, cl, cd, cs};
+        C.eval_exact(t, h, what);
+    });
+}
 int tedd_eval_forcing(tedd_ctx* ctx, double t, double* fcp, double* fT, double* fcl, double* fcd, double* fcs) {
     return guarded(ctx, [&](auto& C) {
         double* h[5] = {fcp, fT, fcl, fcd, fcs};

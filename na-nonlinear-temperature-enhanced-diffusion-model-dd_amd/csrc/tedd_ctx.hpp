@@ -470,6 +470,7 @@ public:
         Ctx* c;
         double t;
         double* out[5];
+        int what = 0;
         template <int CASE, int REACT>
         void run() {
             Ctx& C = *c;
@@ -477,14 +478,15 @@ public:
             Out5 o;
             for (int v = 0; v < 5; ++v) o.v[v] = out[v];
             ExactFn<(CASE == CASE_STREAM ? CASE_POL : CASE)> f{C.grid(), C.model, C.tabs(),
-                                                               mms_time_fill(C.mms_case, C.model, C.mp, t), o};
+                                                               mms_time_fill(C.mms_case, C.model, C.mp, t), o, what};
             C.be.nodes(FAM_MISC, f, 0, C.nrows, C.ncols);
             for (int v = 0; v < 5; ++v) C.mark(out[v], C.full());
         }
     };
-    void eval_exact(double t, double* const h[5]) {
+    void eval_exact(double t, double* const h[5], int what = 0) {
+        if (what < 0 || what > 4) throw InvalidError("what must be 0..4");
         Tmp5 tmp(this);
-        ExactOp op{this, t, {tmp.p[0], tmp.p[1], tmp.p[2], tmp.p[3], tmp.p[4]}};
+        ExactOp op{this, t, {tmp.p[0], tmp.p[1], tmp.p[2], tmp.p[3], tmp.p[4]}, what};
         dispatch(op);
         for (int v = 0; v < 5; ++v)
             if (h[v]) download_field(h[v], op.out[v]);

@@ -457,7 +457,9 @@ TEDD_HD double cs_newton_step(double x, double y, double av, double eta) {
 }
 
 // ------------------------------------------------------------------------------------
-// Exact solution at the nodes (closed-form cases only).
+// Exact solution at the nodes (closed-form cases only).  what: 0 value, 1 d/dt, 2 d/dx, 3 d/dy,
+// 4 Laplacian; entries the forcing terms never use (Laplacian of cp; space derivatives of cs)
+// are returned as NaN.
 template <int CASE>
 struct ExactFn {
     GridDev g;
@@ -465,14 +467,20 @@ struct ExactFn {
     MmsTabs tb;
     MmsTime tm;
     Out5 out;
+    int what;
     TEDD_HD void operator()(int li, int j) const {
         const MmsPt p = mms_node<CASE>(m, tm, tb, li, j);
         const size_t c = at(g, li, j);
-        out.v[0][c] = p.cp;
-        out.v[1][c] = p.T;
-        out.v[2][c] = p.cl;
-        out.v[3][c] = p.cd;
-        out.v[4][c] = p.cs;
+        const double nan = NAN;
+        double r[5];
+        switch (what) {
+            case 1: r[0] = p.cp_t; r[1] = p.T_t; r[2] = p.cl_t; r[3] = p.cd_t; r[4] = p.cs_t; break;
+            case 2: r[0] = p.cp_x; r[1] = p.T_x; r[2] = p.cl_x; r[3] = p.cd_x; r[4] = nan; break;
+            case 3: r[0] = p.cp_y; r[1] = p.T_y; r[2] = p.cl_y; r[3] = p.cd_y; r[4] = nan; break;
+            case 4: r[0] = nan; r[1] = p.T_l; r[2] = p.cl_l; r[3] = p.cd_l; r[4] = nan; break;
+            default: r[0] = p.cp; r[1] = p.T; r[2] = p.cl; r[3] = p.cd; r[4] = p.cs; break;
+        }
+        for (int v = 0; v < 5; ++v) out.v[v][c] = r[v];
     }
 };
 

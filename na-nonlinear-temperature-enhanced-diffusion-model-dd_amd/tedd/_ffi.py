@@ -69,6 +69,7 @@ PROTOTYPES = {
     "tedd_get_residuals": (C.c_int, [C.c_void_p] + [_dptr] * 3),
     "tedd_eval_field": (C.c_int, [C.c_void_p, C.c_double] + [_dptr] * 5),
     "tedd_eval_exact": (C.c_int, [C.c_void_p, C.c_double] + [_dptr] * 5),
+    "tedd_eval_mms": (C.c_int, [C.c_void_p, C.c_double, C.c_int32] + [_dptr] * 5),
     "tedd_eval_forcing": (C.c_int, [C.c_void_p, C.c_double] + [_dptr] * 5),
     "tedd_eval_jacobian": (C.c_int, [C.c_void_p, C.c_int32] + [_dptr] * 5),
     "tedd_error_norms": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(_dptr), _dptr]),
@@ -272,6 +273,11 @@ class Context:
     def eval_exact(self, t):
         out = self._out(5)
         self._check(self._lib.tedd_eval_exact(self._h, float(t), *[_arr(a) for a in out]))
+        return out
+
+    def eval_mms(self, t, what):
+        out = self._out(5)
+        self._check(self._lib.tedd_eval_mms(self._h, float(t), int(what), *[_arr(a) for a in out]))
         return out
 
     def eval_forcing(self, t):

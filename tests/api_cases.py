@@ -1,0 +1,243 @@
+"""Test bodies for the Python mirror of the reference API (tedd.prob1base & co.).  They read like
+the reference's own tests (tests/test_reghcstriple_system.py, tests/test_reghcstriple.py,
+tests/test_time_integration_fwd_euler_full_p1base.py, tests/test_newton_residuals.py) and are
+run twice: on the host twin (CPU suite, small sizes) and on the GPU (full sizes)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import tedd.mms_trial_utils as mtu
+import tedd.prob1_mms_cases as p1mc
+import tedd.prob1base as p1
+from tedd.utils_for_testing import observed_rates_report
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MODEL_SETS = json.load(open(os.path.join(GOLDEN, "model_sets.json")))
+PUBLISHED = json.load(open(os.path.join(GOLDEN, "published_notebook_errors.json")))
+ETA = 50.0
+
+CASES = {
+    "expsin": (p1mc.MMSCaseExpSin, "nb_a", 0.01),
+    "pol": (p1mc.MMSCasePol, "nb_b", 0.01),
+    "peaks_fast1e1": (p1mc.MMSCaseSlowlyChangingPeaks_Fast1e1, "nb_b", 1.0),
+    "nfs_h2_h3": (p1mc.MMSCaseNonFullySmoothPol_cpcsH2_TclcdH3, "nb_a", 1.0),
+}
+
+
+def model_of(name, kind=2):
+    mc = p1.ModelConsts(**MODEL_SETS[name])
+    return p1.DefaultModel02(mc) if kind == 2 else p1.DefaultModel01(mc)
+
+
+def reg_trial(case_cls, model, N, eta=ETA, integrator_cls=None, integrator_params=None, fused=True, M=None):
+    grid = p1.make_uniform_grid(N=N, M=N if M is None else M)
+    common = {"regularization_factor": eta}
+    icls = integrator_cls or p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple
+    iparams = dict(common) if integrator_params is None else integrator_params
+    if icls is p1.ForwardEulerIntegrator:
+        iparams = {}
+    return mtu.MMSTrial(grid=grid, model=model, mms_case_cls=case_cls,
+                        field_cls=p1.SemiDiscreteField_RegHCsTriple,
+                        forcing_terms_cls=p1.ForcingTerms_RegHCsTriple, integrator_cls=icls,
+                        integrator_params=iparams, forcing_terms_params=common, field_params=common,
+                        fused=fused)
+
+
+# ------------------------------------------------------------------------------------------
+def check_classes_instantiation():
+    """reference tests/test_reghcstriple_system.py:120-167"""
+    model = model_of("nb_a")
+    grid = p1.make_uniform_grid(N=5, M=5)
+    case = p1mc.MMSCaseExpSin(grid=p1.make_uniform_grid(N=2, M=2), model=model)
+    forcing = p1.ForcingTerms_RegHCsTriple(mms_case=case, model=model, regularization_factor=ETA)
+    assert forcing.regularization_factor == ETA
+    field = p1.SemiDiscreteField_RegHCsTriple(grid=grid, model=model, forcing_terms=forcing,
+                                              regularization_factor=ETA)
+    assert field.regularization_factor == ETA
+    integ = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple(
+        semi_discrete_field=field, regularization_factor=ETA, num_pc_steps=1, num_newton_iterations=3)
+    assert integ._regularization_factor == ETA
+    assert integ._num_newton_iterations == 3
+    assert integ.num_pc_steps == 1 and integ.num_newton_steps == 1
+    assert integ.semi_discrete_field is field and integ._model is model and integ._grid is grid
+
+
+def check_published_errors(case_name, levels, rel):
+    """The error norms printed in the reference's executed notebooks (spatial studies)."""
+    cls, mset, Tf = CASES[case_name]
+    model = model_of(mset)
+    out = []
+    for lev in PUBLISHED[case_name]["levels"]:
+        N = lev["N"]
+        if N not in levels:
+            continue
+        trial = reg_trial(cls, model, N)
+        summ = trial.run_for_errors(Tf=Tf, dt=(1.0 / N) ** 1.5)
+        assert summ.overall_combined_error == pytest.approx(lev["overall"], rel=rel), (case_name, N)
+        for v, val in lev["per_variable"].items():
+            assert summ.per_variable_sup_errors[v] == pytest.approx(val, rel=1e-4, abs=1e-16), (case_name, N, v)
+        out.append(summ.overall_combined_error)
+    return out
+
+
+def check_fused_equals_stepwise(case_name, N, nsteps_Tf):
+    """The device-fused time loop + norms and the reference's step-by-step loop agree."""
+    cls, mset, _ = CASES[case_name]
+    model = model_of(mset)
+    dt = (1.0 / N) ** 1.5
+    a = reg_trial(cls, model, N, fused=True).run_for_errors(Tf=nsteps_Tf * dt, dt=dt)
+    b = reg_trial(cls, model, N, fused=False).run_for_errors(Tf=nsteps_Tf * dt, dt=dt)
+    assert a.dt_used == b.dt_used
+    assert a.overall_combined_error == pytest.approx(b.overall_combined_error, rel=1e-9)
+    for v in a.per_variable_sup_errors:
+        assert a.per_variable_sup_errors[v] == pytest.approx(b.per_variable_sup_errors[v], rel=1e-7, abs=1e-18)
+
+
+def check_streamed_equals_closed_form(N=8):
+    """Forcing streamed from host callables gives the same step as forcing evaluated in-kernel."""
+    model = model_of("nb_a")
+    grid = p1.make_uniform_grid(N, N)
+    case = p1mc.MMSCaseExpSin(grid=grid, model=model)
+    forcing = p1.ForcingTerms_RegHCsTriple(mms_case=case, model=model, regularization_factor=ETA)
+    f_closed = p1.SemiDiscreteField_RegHCsTriple(grid=grid, model=model, forcing_terms=forcing,
+                                                 regularization_factor=ETA)
+    f_stream = p1.SemiDiscreteField_RegHCsTriple(grid=grid, model=model,
+                                                 forcing_terms=p1.ForcingTermsFromDict(forcing.asdict()),
+                                                 regularization_factor=ETA)
+    assert f_closed._closed_form_source() is forcing and f_stream._closed_form_source() is None
+    S0 = p1.state_from_mms_when(mms_case=case, t=0.0, grid=grid)
+    dt = (1.0 / N) ** 1.5
+    ia = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple(f_closed, regularization_factor=ETA)
+    ib = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple(f_stream, regularization_factor=ETA)
+    Sa, Sb, t = S0, S0, 0.0
+    for _ in range(3):
+        Sa = ia.step(Sa, t0=t, dt=dt)
+        Sb = ib.step(Sb, t0=t, dt=dt)
+        t += dt
+    for v in ("cp", "T", "cl", "cd", "cs"):
+        np.testing.assert_allclose(getattr(Sa, v), getattr(Sb, v), rtol=0, atol=1e-15)
+    for v in ("T", "cl", "cd"):
+        np.testing.assert_allclose(ia.last_residual[v], ib.last_residual[v], rtol=0, atol=1e-15)
+    for a, b in zip((f_closed.Fcp, f_closed.FT, f_closed.Fcl, f_closed.Fcd, f_closed.Fcs),
+                    (f_stream.Fcp, f_stream.FT, f_stream.Fcl, f_stream.Fcd, f_stream.Fcs)):
+        np.testing.assert_allclose(a(S0, 0.1), b(S0, 0.1), rtol=0, atol=1e-15)
+
+
+def check_field_correctness(sizes):
+    """||F(u_exact) - d/dt u_exact||_H decreases with refinement (reference
+    tests/test_reghcstriple_system.py:175-259)."""
+    model = model_of("nb_a")
+    errs = []
+    for n in sizes:
+        grid = p1.make_uniform_grid(N=n, M=n)
+        case = p1mc.MMSCaseExpSin(grid=grid, model=model)
+        forcing = p1.ForcingTerms_RegHCsTriple(mms_case=case, model=model, regularization_factor=ETA)
+        field = p1.SemiDiscreteField_RegHCsTriple(grid=grid, model=model, forcing_terms=forcing,
+                                                  regularization_factor=ETA)
+        t = 0.1
+        S = p1.state_from_mms_when(mms_case=case, t=t, grid=grid)
+        F = {"cp": field.Fcp(S, t), "T": field.FT(S, t), "cl": field.Fcl(S, t), "cd": field.Fcd(S, t),
+             "cs": field.Fcs(S, t)}
+        dte = {v: getattr(case, "dt_" + v)(t, grid.xx, grid.yy) for v in F}
+        errs.append(np.sqrt(sum(grid.norm_H(F[v] - dte[v]) ** 2 for v in F)))
+    assert errs[-1] < errs[0]
+    if len(errs) >= 3:
+        observed_rates_report(errors=errs, expected_rate=2.0, tolerance=0.5, cmp_type="least")
+    return errs
+
+
+def check_spatial_convergence(sizes):
+    """reference tests/test_reghcstriple_system.py:279-342"""
+    model = model_of("nb_a")
+    dt = 5e-6
+    params = {"regularization_factor": ETA, "num_pc_steps": 1, "num_newton_iterations": 5, "consec_xs_rtol": 1e-7}
+    errs = [reg_trial(p1mc.MMSCaseExpSin, model, n, integrator_params=params).run_for_errors(Tf=dt, dt=dt)
+            .overall_combined_error for n in sizes]
+    observed_rates_report(errors=errs, expected_rate=2.0, tolerance=0.3, cmp_type="least")
+    return errs
+
+
+def check_temporal_convergence(N, dts):
+    """reference tests/test_reghcstriple_system.py:345-416 (num_newton_iterations=1000, rtol 1e-9)"""
+    model = model_of("nb_a")
+    params = {"regularization_factor": ETA, "num_pc_steps": 1, "num_newton_iterations": 1000,
+              "consec_xs_rtol": 1e-9}
+    errs = [reg_trial(p1mc.MMSCaseExpSin, model, N, integrator_params=params).run_for_errors(Tf=dt, dt=dt)
+            .overall_combined_error for dt in dts]
+    observed_rates_report(errors=errs, expected_rate=2.0, tolerance=0.3, cmp_type="least")
+    return errs
+
+
+def check_pc_beats_forward_euler():
+    """reference tests/test_reghcstriple_system.py:419-483"""
+    model = model_of("nb_a")
+    dt = 5e-4
+    params = {"regularization_factor": ETA, "num_pc_steps": 1, "num_newton_iterations": 1, "consec_xs_rtol": 1e-7}
+    e_pc = reg_trial(p1mc.MMSCaseExpSin, model, 4, integrator_params=params).run_for_errors(Tf=3 * dt, dt=dt)
+    e_fe = reg_trial(p1mc.MMSCaseExpSin, model, 4, integrator_cls=p1.ForwardEulerIntegrator).run_for_errors(Tf=3 * dt, dt=dt)
+    assert e_pc.overall_combined_error < e_fe.overall_combined_error
+
+
+def check_forward_euler_order(grid_n, t_test):
+    """reference tests/test_time_integration_fwd_euler_full_p1base.py:123-198 (CsTriple, ExpSin)"""
+    model = model_of("fe")
+    grid = p1.make_uniform_grid(N=grid_n, M=grid_n)
+    trial = mtu.MMSTrial(grid=grid, model=model, mms_case_cls=p1mc.MMSCaseExpSin,
+                         field_cls=p1.SemiDiscreteField_CsTriple, forcing_terms_cls=p1.ForcingTerms_CsTriple,
+                         integrator_cls=p1.ForwardEulerIntegrator)
+    max_D = max(model.DT, model.Dl_max, model.Dd_max, 1e-9)
+    base_dt = min(4e-4, 0.5 * (1.0 / grid_n) ** 2 / (4.0 * max_D))
+    # one-step consistency (…:77-120)
+    dt_test = min(1e-2, (1.0 / grid_n) ** 2 / (4.0 * max_D) * 0.5)
+    summ = trial.run_for_errors(Tf=t_test + dt_test, dt=dt_test, t0=t_test)
+    for v in ("cp", "T", "cl", "cd", "cs"):
+        assert summ.per_variable_sup_errors[v] == pytest.approx(0.0, abs=100 * dt_test, rel=1e-3)
+    return base_dt
+
+
+def check_newton_residuals(case_name, N=8, dt=1e-4, steps=(1, 20)):
+    """||last_residual||_H < 1e-9 after 1 and 20 steps with 5 Newton steps
+    (reference tests/test_newton_residuals.py:116-124, run there for CsTriple/HCsTriple)."""
+    cls, mset, _ = CASES[case_name]
+    model = model_of(mset)
+    grid = p1.make_uniform_grid(N, N)
+    case = cls(grid=grid, model=model)
+    forcing = p1.ForcingTerms_RegHCsTriple(mms_case=case, model=model, regularization_factor=ETA)
+    field = p1.SemiDiscreteField_RegHCsTriple(grid=grid, model=model, forcing_terms=forcing,
+                                              regularization_factor=ETA)
+    integ = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple(
+        field, regularization_factor=ETA, num_newton_steps=5)
+    S = p1.state_from_mms_when(mms_case=case, t=0.0, grid=grid)
+    t = 0.0
+    for k in range(1, max(steps) + 1):
+        S = integ.step(S, t0=t, dt=dt)
+        t += dt
+        if k in steps:
+            for v in ("T", "cl", "cd"):
+                assert grid.norm_H(integ.last_residual[v]) < 1e-9, (case_name, k, v)
+
+
+def check_error_behaviour():
+    model = model_of("nb_a")
+    trial = reg_trial(p1mc.MMSCaseExpSin, model, 4)
+    S0 = trial.initial_state
+    with pytest.raises(AssertionError):
+        trial.integrator.step(S0, t0=0.0, dt=0.0)          # reference: assert dt > 0
+    with pytest.raises(AttributeError):
+        S0.T = np.zeros_like(S0.T)                          # StateVars is immutable
+    with pytest.raises(ValueError):
+        S0.with_changes(foo=1)
+    # model constants mutated in place are seen by the next step
+    S1 = trial.integrator.step(S0, t0=0.0, dt=1e-3)
+    trial.integrator._model.Kd = 0.5
+    S1b = trial.integrator.step(S0, t0=0.0, dt=1e-3)
+    assert np.max(np.abs(S1b.cs - S1.cs)) > 1e-8
+    # a non-device field is refused, not silently run on the CPU
+    class Dummy:
+        pass
+    dummy = Dummy()
+    dummy.model, dummy.grid = model, trial.grid
+    with pytest.raises(NotImplementedError):
+        p1.ForwardEulerIntegrator(dummy).step(S0, t0=0.0, dt=1e-3)

@@ -1,0 +1,60 @@
+"""The Python mirror of the reference API, exercised on the host twin of the device library
+(CPU suite; the GPU suite repeats these on libtedd_hip.so with the reference's full sizes)."""
+import numpy as np
+import pytest
+
+import api_cases as ac
+from test_twin_cabi_parity import TWIN, build_twin
+from tedd import _ffi
+
+
+@pytest.fixture(scope="module", autouse=True)
+def twin_library():
+    build_twin()
+    _ffi.use_library(TWIN)
+    yield
+
+
+def test_classes_instantiation():
+    ac.check_classes_instantiation()
+
+
+@pytest.mark.parametrize("case,levels,rel", [("expsin", (2, 4, 8, 16, 32), 2e-9), ("pol", (2, 4, 8, 16), 5e-6),
+                                             ("peaks_fast1e1", (2, 4, 8), 2e-9), ("nfs_h2_h3", (2, 4, 8), 2e-9)])
+def test_published_notebook_errors(case, levels, rel):
+    ac.check_published_errors(case, levels, rel)
+
+
+@pytest.mark.parametrize("case", ["expsin", "pol", "peaks_fast1e1", "nfs_h2_h3"])
+def test_fused_loop_equals_stepwise_loop(case):
+    ac.check_fused_equals_stepwise(case, 8, 6)
+
+
+def test_streamed_forcing_equals_closed_form():
+    ac.check_streamed_equals_closed_form()
+
+
+def test_field_correctness():
+    ac.check_field_correctness([8, 16, 32])
+
+
+def test_spatial_convergence():
+    ac.check_spatial_convergence([8, 16, 32])
+
+
+def test_pc_beats_forward_euler():
+    ac.check_pc_beats_forward_euler()
+
+
+@pytest.mark.parametrize("grid_n", [5, 15])
+def test_forward_euler_consistency(grid_n):
+    ac.check_forward_euler_order(grid_n, 0.05)
+
+
+@pytest.mark.parametrize("case", ["expsin", "pol"])
+def test_newton_residuals(case):
+    ac.check_newton_residuals(case)
+
+
+def test_error_behaviour():
+    ac.check_error_behaviour()

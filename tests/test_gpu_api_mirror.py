@@ -1,0 +1,71 @@
+"""GPU run of the Python mirror of the reference API: the reference's own system tests for the
+RegHCsTriple predictor-corrector and forward Euler, plus the error norms its notebooks printed,
+at the reference's sizes (up to the finest convergence-study mesh, N=256)."""
+import numpy as np
+import pytest
+
+import api_cases as ac
+from tedd import _ffi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def hip_library():
+    import torch
+    assert torch.cuda.is_available()
+    _ffi.use_library(_ffi.DEFAULT_LIBRARY)
+    yield
+
+
+def test_classes_instantiation():
+    ac.check_classes_instantiation()
+
+
+@pytest.mark.parametrize("case,levels,rel", [
+    ("expsin", (2, 4, 8, 16, 32, 64, 128, 256), 2e-9),      # N=256: the published finest-mesh run (41 steps)
+    ("pol", (2, 4, 8, 16, 32, 64, 128, 256), 5e-6),
+    ("peaks_fast1e1", (2, 4, 8, 16, 32, 64), 2e-9),
+    ("nfs_h2_h3", (2, 4, 8, 16, 32, 64), 2e-9)])
+def test_published_notebook_errors(case, levels, rel):
+    ac.check_published_errors(case, levels, rel)
+
+
+@pytest.mark.parametrize("case", ["expsin", "pol", "peaks_fast1e1", "nfs_h2_h3"])
+def test_fused_loop_equals_stepwise_loop(case):
+    ac.check_fused_equals_stepwise(case, 16, 10)
+
+
+def test_streamed_forcing_equals_closed_form():
+    ac.check_streamed_equals_closed_form(16)
+
+
+def test_field_correctness():
+    ac.check_field_correctness([8, 16, 32, 64])
+
+
+def test_spatial_convergence():
+    ac.check_spatial_convergence([8, 16, 32])
+
+
+def test_temporal_convergence():
+    ac.check_temporal_convergence(128, 16 * np.array([4e-3, 2e-3, 1e-3, 5e-4, 2.5e-4, 1.25e-4, 6.25e-5]))
+
+
+def test_pc_beats_forward_euler():
+    ac.check_pc_beats_forward_euler()
+
+
+@pytest.mark.parametrize("grid_n", [5, 15, 35])
+@pytest.mark.parametrize("t_test", [0.01, 0.05, 1.0, 5.0])
+def test_forward_euler_consistency(grid_n, t_test):
+    ac.check_forward_euler_order(grid_n, t_test)
+
+
+@pytest.mark.parametrize("case", ["expsin", "pol", "peaks_fast1e1", "nfs_h2_h3"])
+def test_newton_residuals(case):
+    ac.check_newton_residuals(case)
+
+
+def test_error_behaviour():
+    ac.check_error_behaviour()
