@@ -66,10 +66,12 @@ class HaloExchange:
     """Refreshes the ghost rows of a list of (local_rows x pitch) tensors with one send and one
     receive per neighbour (all fields packed into one message)."""
 
-    def __init__(self, slab: Slab, group=None):
+    def __init__(self, slab: Slab, group=None, stage_through_host=None):
         self.slab = slab
         self.group = group
         self._bufs = {}
+        # gloo has no device-memory point-to-point: stage device rows through pinned host buffers
+        self.stage_through_host = stage_through_host
 
     def _buf(self, key, shape, like):
         b = self._bufs.get(key)
@@ -82,6 +84,11 @@ class HaloExchange:
         s = self.slab
         if s.world == 1:
             return
+        stage = self.stage_through_host
+        if stage is None:
+            stage = fields[0].is_cuda and dist.get_backend(self.group) == "gloo"
+        if stage:
+            return self._exchange_staged(fields)
         o_lo, o_hi = s.owned_local
         nf = len(fields)
         pitch = fields[0].shape[1]
@@ -112,6 +119,32 @@ class HaloExchange:
                 f[a:b].copy_(recv[k])
 
 
+    def _exchange_staged(self, fields):
+        s = self.slab
+        o_lo, o_hi = s.owned_local
+        ops, unpack = [], []
+        if s.rank > 0:
+            n_send = min(s.ghost, s.n_rows - s.row_lo)
+            send = torch.stack([f[o_lo:o_lo + n_send] for f in fields]).cpu()
+            recv = torch.empty((len(fields), s.ghost_lo, fields[0].shape[1]), dtype=fields[0].dtype)
+            ops += [dist.P2POp(dist.isend, send, s.rank - 1, self.group),
+                    dist.P2POp(dist.irecv, recv, s.rank - 1, self.group)]
+            unpack.append((recv, 0, s.ghost_lo))
+        if s.rank < s.world - 1:
+            n_send = min(s.ghost, s.row_hi)
+            send = torch.stack([f[o_hi - n_send:o_hi] for f in fields]).cpu()
+            recv = torch.empty((len(fields), s.ghost_hi, fields[0].shape[1]), dtype=fields[0].dtype)
+            ops += [dist.P2POp(dist.isend, send, s.rank + 1, self.group),
+                    dist.P2POp(dist.irecv, recv, s.rank + 1, self.group)]
+            unpack.append((recv, o_hi, o_hi + s.ghost_hi))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for recv, a, b in unpack:
+            r = recv.to(fields[0].device)
+            for k, f in enumerate(fields):
+                f[a:b].copy_(r[k])
+
+
 class _DeviceArray:
     """Exposes a raw device pointer through __cuda_array_interface__ so torch can wrap it."""
 
@@ -121,6 +154,17 @@ class _DeviceArray:
 
 
 def wrap_device_fields(ptrs, rows, pitch, device):
+    """torch views (rows x pitch, float64) of the context's state arrays.  On a CPU device the
+    addresses are host addresses (the host-compiled test twin of the library)."""
+    if device.type == "cpu":
+        import ctypes
+
+        import numpy as np
+        out = []
+        for p in ptrs:
+            buf = (ctypes.c_double * (rows * pitch)).from_address(int(p))
+            out.append(torch.from_numpy(np.frombuffer(buf, dtype=np.float64).reshape(rows, pitch)))
+        return out
     return [torch.as_tensor(_DeviceArray(p, rows, pitch), device=device) for p in ptrs]
 
 

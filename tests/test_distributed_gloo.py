@@ -1,0 +1,141 @@
+"""Row-slab decomposition + ghost-row exchange, world_size 2 and 3 over gloo on CPU.
+
+Each rank drives the host twin of the device library on its slab (same context code, ghost-row
+bookkeeping and C ABI as the HIP library) and exchanges ghost rows with tedd.distributed.  The
+decomposed run must reproduce the single-slab run bit for bit on every owned row, because a
+slab performs exactly the arithmetic of the corresponding rows of the whole mesh."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "na-nonlinear-temperature-enhanced-diffusion-model-dd_amd"))
+sys.path.insert(0, HERE)
+
+from tedd.distributed import HaloExchange, SlabStepper, partition_rows  # noqa: E402
+
+NB_A = [8.3144621, 1.60217662e-19, 1e-3, 1e-3, 1e-3, 1e-3, 1e-3, 1e-5, 1e-5, 1e-9, 1e-2, 1.0, 1e-6, 1e-5,
+        1.60217662e-19 / 8.3144621, 5e-2, 300.0]
+STRESS = [8.3144621, 1.60217662e-19, 0.11, 0.23, 0.37, 0.19, 2e-2, 3e-2, 0.4, 0.03, 0.2, 1.5, 1e-2, 0.3, 50.0,
+          5e-2, 300.0]
+
+
+def test_partition_covers_all_rows():
+    for n_rows in (9, 33, 257, 16385):
+        for world in (1, 2, 3, 8):
+            if n_rows // world < 2:
+                continue
+            slabs = [partition_rows(n_rows, world, r, 2) for r in range(world)]
+            assert slabs[0].row_lo == 0 and slabs[-1].row_hi == n_rows
+            for a, b in zip(slabs[:-1], slabs[1:]):
+                assert a.row_hi == b.row_lo
+            sizes = [s.row_hi - s.row_lo for s in slabs]
+            assert max(sizes) - min(sizes) <= 1
+            assert slabs[0].ghost_lo == 0 and slabs[-1].ghost_hi == 0
+            if world > 1:
+                assert slabs[0].ghost_hi == 2 and slabs[-1].ghost_lo == 2
+    with pytest.raises(ValueError):
+        partition_rows(9, 4, 0, 3)   # slabs of 2 rows cannot feed 3 ghost rows
+    with pytest.raises(ValueError):
+        partition_rows(9, 2, 0, 0)
+
+
+def _worker(rank, world, port, case, N, M, nsteps, kind, consts, sweeps, ghost, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_twin_cabi_parity import TWIN
+        from tedd import _ffi
+        _ffi.use_library(TWIN)
+        x = np.linspace(0, 1, N + 1) ** 1.1
+        y = np.linspace(0, 1, M + 1)
+        slab = partition_rows(N + 1, world, rank, ghost)
+        ctx = _ffi.Context(x, y, consts, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+                           mms_case=case, row_lo=slab.row_lo, row_hi=slab.row_hi, ghost=slab.ghost)
+        assert ctx.nrows == slab.local_rows and ctx.row_offset == slab.row_offset
+        stepper = SlabStepper(ctx, slab, torch.device("cpu"))
+        ctx.set_state_exact(0.0)
+        dt, t = 0.01, 0.0
+        norms = []
+        for _ in range(nsteps):
+            if kind == "pc":
+                stepper.step_pc(t, dt, jacobi_sweeps=sweeps)
+            else:
+                stepper.step_feuler(t, dt)
+            t += dt
+            local = torch.from_numpy(ctx.error_norms(t))
+            dist.all_reduce(local)
+            norms.append(local.numpy().copy())
+        state = ctx.get_state()
+        a, b = slab.owned_local
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=slab.row_lo, hi=slab.row_hi,
+                 norms=np.array(norms), **{f"f{k}": s[a:b] for k, s in enumerate(state)})
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _single(case, N, M, nsteps, kind, consts, sweeps):
+    from test_twin_cabi_parity import TWIN, build_twin
+    from tedd import _ffi
+    build_twin()
+    _ffi.use_library(TWIN)
+    x = np.linspace(0, 1, N + 1) ** 1.1
+    y = np.linspace(0, 1, M + 1)
+    ctx = _ffi.Context(x, y, consts, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0, mms_case=case)
+    ctx.set_state_exact(0.0)
+    dt, t = 0.01, 0.0
+    norms = []
+    for _ in range(nsteps):
+        if kind == "pc":
+            ctx.step_pc(t, dt, jacobi_sweeps=sweeps)
+        else:
+            ctx.step_feuler(t, dt)
+        t += dt
+        norms.append(ctx.error_norms(t))
+    out = ctx.get_state()
+    ctx.close()
+    return out, np.array(norms)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("kind,case,consts", [("pc", 1, NB_A), ("pc", 0, STRESS), ("fe", 2, NB_A)])
+def test_slab_run_equals_single_domain(world, kind, case, consts, tmp_path):
+    N, M, nsteps = 47, 21, 4
+    sweeps = [4, 3, 2]
+    ghost = sum(sweeps) + 2 if kind == "pc" else 1
+    ref_state, ref_norms = _single(case, N, M, nsteps, kind, consts, sweeps)
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, case, N, M, nsteps, kind, consts, sweeps, ghost, str(tmp_path)),
+             nprocs=world, join=True)
+    rows = 0
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        lo, hi = int(z["lo"]), int(z["hi"])
+        for k in range(5):
+            np.testing.assert_array_equal(z[f"f{k}"], ref_state[k][lo:hi])   # bit for bit
+        # the global norms are sums over ranks: equal up to the summation order
+        np.testing.assert_allclose(z["norms"], ref_norms, rtol=1e-12, atol=1e-300)
+        rows += hi - lo
+    assert rows == N + 1
+
+
+def test_too_few_ghost_rows_is_an_error(tmp_path):
+    """A step that applies more stencils than there are ghost rows must fail loudly."""
+    from test_twin_cabi_parity import TWIN, build_twin
+    from tedd import _ffi
+    build_twin()
+    _ffi.use_library(TWIN)
+    x = np.linspace(0, 1, 33)
+    ctx = _ffi.Context(x, x, NB_A, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0, mms_case=1,
+                       row_lo=10, row_hi=20, ghost=3)
+    ctx.set_state_exact(0.0)
+    with pytest.raises(ValueError, match="ghost"):
+        ctx.step_pc(0.0, 0.01, jacobi_sweeps=[4, 3, 2])
+    ctx.close()

@@ -1,0 +1,72 @@
+"""Two slabs on one MI355X (two processes sharing cuda:0; ghost rows staged through the host
+over gloo, since two ranks cannot share one device under RCCL): the HIP slab path must
+reproduce the single-slab HIP run bit for bit on every owned row."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "na-nonlinear-temperature-enhanced-diffusion-model-dd_amd"))
+
+pytestmark = pytest.mark.gpu
+
+NB_A = [8.3144621, 1.60217662e-19, 1e-3, 1e-3, 1e-3, 1e-3, 1e-3, 1e-5, 1e-5, 1e-9, 1e-2, 1.0, 1e-6, 1e-5,
+        1.60217662e-19 / 8.3144621, 5e-2, 300.0]
+N, M, NSTEPS, SWEEPS = 300, 130, 3, [5, 3, 2]
+
+
+def _run(ctx, stepper=None):
+    ctx.set_state_exact(0.0)
+    dt, t = (1.0 / N) ** 1.5, 0.0
+    for _ in range(NSTEPS):
+        if stepper is None:
+            ctx.step_pc(t, dt, jacobi_sweeps=SWEEPS)
+        else:
+            stepper.step_pc(t, dt, jacobi_sweeps=SWEEPS)
+        t += dt
+    return ctx.get_state()
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tedd import _ffi
+        from tedd.distributed import SlabStepper, partition_rows
+        torch.cuda.set_device(0)
+        x = np.linspace(0, 1, N + 1)
+        y = np.linspace(0, 1, M + 1)
+        slab = partition_rows(N + 1, world, rank, sum(SWEEPS) + 2)
+        ctx = _ffi.Context(x, y, NB_A, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+                           mms_case=_ffi.MMS_EXPSIN, row_lo=slab.row_lo, row_hi=slab.row_hi, ghost=slab.ghost)
+        state = _run(ctx, SlabStepper(ctx, slab, torch.device("cuda", 0)))
+        a, b = slab.owned_local
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=slab.row_lo, hi=slab.row_hi,
+                 **{f"f{k}": s[a:b] for k, s in enumerate(state)})
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_slabs_equal_single_slab(tmp_path):
+    from tedd import _ffi
+    _ffi.use_library(_ffi.DEFAULT_LIBRARY)
+    x = np.linspace(0, 1, N + 1)
+    y = np.linspace(0, 1, M + 1)
+    ctx = _ffi.Context(x, y, NB_A, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+                       mms_case=_ffi.MMS_EXPSIN)
+    ref = _run(ctx)
+    ctx.close()
+    port = 29700 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        lo, hi = int(z["lo"]), int(z["hi"])
+        for k in range(5):
+            np.testing.assert_array_equal(z[f"f{k}"], ref[k][lo:hi])
