@@ -75,6 +75,10 @@ const char* tedd_last_error(const tedd_ctx* ctx); /* ctx may be NULL: error of t
  * place between steps, e.g. tests/test_time_integrator_hcs_triple.py:377-387). */
 int tedd_set_model(tedd_ctx* ctx, const double consts[17], int32_t model_kind, double eta,
                    const double mms_params[8]);
+/* Execution options.  "blocked_solve" (default 1): solve the Newton systems with the LDS-blocked
+ * kernel chain (several Jacobi sweeps per launch) instead of one launch per sweep.
+ * "blocked_hmax": sweeps fused per launch (0 = automatic). */
+int tedd_set_option(tedd_ctx* ctx, const char* name, double value);
 /* Use the caller's HIP stream (hipStream_t passed as void*) for all subsequent work. */
 int tedd_set_stream(tedd_ctx* ctx, void* hip_stream);
 int tedd_sync(tedd_ctx* ctx);

@@ -85,6 +85,12 @@ int tedd_set_model(tedd_ctx* ctx, const double consts[17], int32_t model_kind, d
         C.set_model(consts, model_kind, eta, mms_params);
     });
 }
+int tedd_set_option(tedd_ctx* ctx, const char* name, double value) {
+    return guarded(ctx, [&](auto& C) {
+        if (!name) throw tedd::InvalidError("name is null");
+        C.set_option(name, value);
+    });
+}
 int tedd_set_stream(tedd_ctx* ctx, void* s) {
     return guarded(ctx, [&](auto& C) { C.be.set_stream(s); });
 }

@@ -626,8 +626,103 @@ public:
         dispatch(op);
     }
 
+    // valid range of a launch that reads `uses` with a halo of `depth` rows (+1 where stencil)
+    Range need_depth(std::initializer_list<Use> uses, int depth) const {
+        Range r = full();
+        for (const Use& u : uses) {
+            if (!u.p) continue;
+            Range v = vof(u.p);
+            for (int d = 0; d < depth + (u.stencil ? 1 : 0); ++d) v = shrink(v);
+            r.lo = std::max(r.lo, v.lo);
+            r.hi = std::min(r.hi, v.hi);
+        }
+        if (r.hi < r.lo) r.hi = r.lo;
+        return r;
+    }
+
+    // options
+    int opt_blocked = 1;      // use the LDS-blocked solve where the backend has it
+    int opt_hmax = 0;         // sweeps fused per launch (0 = automatic)
+
+    template <int VAR, int CASE, int REACT>
+    void newton_solve_blocked(const StepParams& p, const ForcingSrc& f1, const NewtonIn& a, double* unew, int nsweeps,
+                              int slot_id) {
+        if constexpr (Backend::kHasBlockedSolve) {
+            const int fam = (VAR == VAR_T) ? FAM_SOLVE_T : (VAR == VAR_CL) ? FAM_SOLVE_CL : FAM_SOLVE_CD;
+            int remaining = nsweeps - 1;  // the first launch also produces delta^1
+            int hmax = opt_hmax > 0 ? opt_hmax : ((size_t)nrows * ncols > (size_t)1 << 20 ? 8 : 12);
+            hmax = std::min(hmax, 24);
+            const int L = std::max(1, (remaining + hmax - 1) / hmax);
+            BlockedArgs A;
+            A.g = grid();
+            A.m = model;
+            A.tb = tabs();
+            A.f1 = f1;
+            A.a = a;
+            A.dt = p.dt;
+            A.stats = reinterpret_cast<unsigned long long*>(d_red + 2 * slot_id);
+            A.tiles_x = 0;
+            double* rhs = (L > 1) ? B(RHS) : nullptr;
+            double* dbuf[2] = {L > 1 ? B(DA) : nullptr, L > 2 ? B(DB) : nullptr};
+            const double* din = nullptr;
+            for (int l = 0; l < L; ++l) {
+                const int ns = (remaining + (L - l) - 1) / (L - l);
+                remaining -= ns;
+                const bool first = (l == 0), lastl = (l == L - 1);
+                A.H = ns;
+                A.nsweeps = ns;
+                Range r;
+                if (first) {
+                    if (VAR == VAR_T)
+                        r = need_depth({{a.cp1, false}, {a.To, true}, {a.YT, false}}, ns);
+                    else if (VAR == VAR_CL)
+                        r = need_depth({{a.cp1, true}, {a.To, true}, {a.clo, true}, {a.Tn, true}, {a.Ycl, false}}, ns);
+                    else
+                        r = need_depth({{a.cp1, true}, {a.To, true}, {a.cdo, true}, {a.clo, false}, {a.cs1, false},
+                                        {a.Tn, true}, {a.cln, false}, {a.Ycd, false}}, ns);
+                } else {
+                    if (VAR == VAR_T)
+                        r = need_depth({{a.cp1, false}, {rhs, false}, {din, false}}, ns);
+                    else if (VAR == VAR_CL)
+                        r = need_depth({{a.cp1, true}, {a.To, true}, {rhs, false}, {din, false}}, ns);
+                    else
+                        r = need_depth({{a.cp1, true}, {a.To, true}, {a.clo, false}, {a.cs1, false}, {rhs, false},
+                                        {din, false}}, ns);
+                }
+                A.r0 = r.lo;
+                A.r1 = r.hi;
+                A.rhs_in = first ? nullptr : rhs;
+                A.d_in = din;
+                A.rhs_out = (first && !lastl) ? rhs : nullptr;
+                double* dout = lastl ? nullptr : dbuf[l & 1];
+                A.d_out = dout;
+                A.u_out = lastl ? unew : nullptr;
+                if (first && lastl)
+                    be.template solve_blocked<VAR, CASE, REACT, true, true>(fam, A, ncols);
+                else if (first)
+                    be.template solve_blocked<VAR, CASE, REACT, true, false>(fam, A, ncols);
+                else if (lastl)
+                    be.template solve_blocked<VAR, CASE_STREAM, REACT, false, true>(fam, A, ncols);
+                else
+                    be.template solve_blocked<VAR, CASE_STREAM, REACT, false, false>(fam, A, ncols);
+                if (first && !lastl) mark(rhs, r);
+                if (lastl)
+                    mark(unew, r);
+                else
+                    mark(dout, r);
+                din = dout;
+            }
+        }
+    }
+
     template <int VAR, int CASE, int REACT>
     void newton_solve(const StepParams& p, const ForcingSrc& f1, const NewtonIn& a, double* unew, int nsweeps, int slot_id) {
+        if constexpr (Backend::kHasBlockedSolve) {
+            if (opt_blocked) {
+                newton_solve_blocked<VAR, CASE, REACT>(p, f1, a, unew, nsweeps, slot_id);
+                return;
+            }
+        }
         const GridDev g = grid();
         double* rhs = B(RHS);
         double* da = B(DA);
@@ -649,7 +744,7 @@ public:
         double* din = da;
         double* dout = db;
         for (int k = 2; k <= nsweeps; ++k) {
-            Range rk = need({{din, true}, {rhs, false}});
+            Range rk = need({{din, true}, {rhs, false}, {a.cp1, VAR != VAR_T}, {VAR != VAR_T ? a.To : nullptr, true}});
             if (k < nsweeps) {
                 JacobiFn<VAR, REACT, false> fj{g, model, a, rhs, din, dout, p.dt};
                 be.nodes(fam_jac, fj, rk.lo, rk.hi, ncols);
@@ -824,6 +919,15 @@ public:
         for (int v = 0; v < 3; ++v)
             if (h[v]) download_field(h[v], op.out[v]);
         be.sync();
+    }
+
+    void set_option(const std::string& name, double value) {
+        if (name == "blocked_solve")
+            opt_blocked = value != 0.0;
+        else if (name == "blocked_hmax")
+            opt_hmax = (int)value;
+        else
+            throw InvalidError("unknown option: " + name);
     }
 
     void get_stats(tedd_step_stats* s) {

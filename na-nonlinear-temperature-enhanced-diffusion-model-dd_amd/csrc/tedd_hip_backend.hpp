@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "tedd_blocked.hpp"
 #include "tedd_ctx.hpp"
 
 namespace tedd {
@@ -209,6 +210,7 @@ struct CorrectClosedFn {
 };
 
 struct HipBackend {
+    static constexpr bool kHasBlockedSolve = true;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int device = -1;
@@ -375,6 +377,20 @@ struct HipBackend {
         tiling(r0, r1, ncols, tx, nt, nb);
         hipLaunchKernelGGL(k_nodes_sum<F>, dim3(nb), dim3(kTileX, kTileY), 0, stream, f, r0, r1, ncols, tx, nt, d_partials);
         hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64), 0, stream, d_partials, nb, (int)F::NR, dev_out);
+        TEDD_HIP(hipGetLastError());
+    }
+    // one launch of the LDS-blocked Newton solve chain (tedd_blocked.hpp)
+    template <int VAR, int CASE, int REACT, bool FIRST, bool LAST>
+    void solve_blocked(int fam, BlockedArgs A, int ncols) {
+        if (A.r1 <= A.r0) return;
+        if (A.H < 0 || A.H > 24 || A.nsweeps < 0 || A.nsweeps > A.H) throw std::runtime_error("bad blocked-solve depth");
+        Scope sc(this, fam);
+        const int TI = kBT - 2 * A.H;
+        A.tiles_x = (ncols + TI - 1) / TI;
+        const long long nt = (long long)A.tiles_x * ((A.r1 - A.r0 + TI - 1) / TI);
+        if (nt > 0x7fffffffLL) throw std::runtime_error("mesh too large for the tile index");
+        hipLaunchKernelGGL((k_solve_blocked<VAR, CASE, REACT, FIRST, LAST>), dim3((unsigned)nt), dim3(kTileX, kTileY), 0,
+                           stream, A);
         TEDD_HIP(hipGetLastError());
     }
     template <int CASE, int REACT>

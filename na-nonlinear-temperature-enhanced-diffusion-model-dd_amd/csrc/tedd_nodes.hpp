@@ -229,6 +229,50 @@ TEDD_HD void newton_row(const ModelC& m, const GridDev& g, const NewtonIn& a, in
     os = dt * r.s;
 }
 
+// Right-hand side of the Newton system for v at an interior node (prob1base.py:3025-3036,
+// 3068-3073, 3102-3108): rhs_T = Y_T - (2 T - dt F_T(S',t1)); rhs_cl = Y_cl - 2 cl + dt F_cl(S',t1)
+// + dt (dFcl/dT)(Tn - T); rhs_cd = Y_cd - 2 cd + dt F_cd(S',t1) + dt (dFcd/dT)(Tn - T)
+// + dt (dFcd/dcl)(cln - cl).
+template <int VAR, int CASE, int REACT>
+TEDD_HD double newton_rhs_value(const GridDev& g, const ModelC& m, const MmsTabs& tb, const ForcingSrc& f1,
+                                const NewtonIn& a, double dt, int li, int j) {
+    const size_t c = at(g, li, j);
+    const Geo ge = geo_at(g, li, j);
+    double fv;
+    if (CASE == CASE_STREAM) {
+        fv = f1.f[VAR][c];
+    } else {
+        const MmsPt p = mms_node<CASE>(m, f1.tm, tb, li, j);
+        fv = (VAR == VAR_T) ? mms_fT(m, p) : (VAR == VAR_CL) ? mms_fcl(m, p) : mms_fcd<REACT>(m, p);
+    }
+    double r;
+    if (VAR == VAR_T) {
+        const St5 T = load5(a.To, g, li, j);
+        r = a.YT[c] - (2.0 * T.c - dt * (fv + rhs_T(m, ge, T, a.cp1[c])));
+    } else if (VAR == VAR_CL) {
+        const St5 cp = load5(a.cp1, g, li, j), T = load5(a.To, g, li, j), cl = load5(a.clo, g, li, j);
+        const double F = fv + rhs_cl(m, ge, faces_Dl(m, cp), T, cl, cp.c);
+        // coupling  dt * (dFcl/dT) (Tn - To), boundary entries of (Tn - To) dropped
+        const int i = g.i0 + li;
+        const double w_ok = (i > 1) ? 1.0 : 0.0, e_ok = (i < g.N - 1) ? 1.0 : 0.0;
+        const Coef5 k = jac_T_Fcl(m, ge, cl, w_ok, e_ok);
+        const double ww = a.Tn[c - g.ld] - T.w, we = a.Tn[c + g.ld] - T.e;
+        r = a.Ycl[c] - 2.0 * cl.c + dt * F + dt * (k.e * we + k.w * ww);
+    } else {
+        const St5 cp = load5(a.cp1, g, li, j), T = load5(a.To, g, li, j), cd = load5(a.cdo, g, li, j);
+        const double clc = a.clo[c], csc = a.cs1[c];
+        const double F = fv + rhs_cd_diffusion(ge, faces_Dd(m, cp, T), cd) + reaction<REACT>(m, clc, cd.c, csc);
+        // coupling with (Tn - To) keeps the boundary entries of the increment
+        const Coef5 k = jac_T_Fcd(ge, faces_dDd_dT(m, cp, T), cd);
+        const St5 Tn = load5(a.Tn, g, li, j);
+        const double JTw = k.c * (Tn.c - T.c) + k.e * (Tn.e - T.e) + k.w * (Tn.w - T.w) + k.n * (Tn.n - T.n) +
+                           k.s * (Tn.s - T.s);
+        const double Jclw = jac_cl_Fcd_diag<REACT>(m, cd.c, csc) * (a.cln[c] - clc);
+        r = a.Ycd[c] - 2.0 * cd.c + dt * F + dt * JTw + dt * Jclw;
+    }
+    return r;
+}
+
 // K_rhs: right-hand side of the Newton system for v and the first Jacobi iterate
 // delta^1 = rhs/diag (the iterate after one sweep from delta^0 = 0).
 template <int VAR, int CASE, int REACT>
@@ -248,44 +292,32 @@ struct NewtonRhsFn {
             d1[c] = 0.0;
             return;
         }
-        const Geo ge = geo_at(g, li, j);
-        double fv;
-        if (CASE == CASE_STREAM) {
-            fv = f1.f[VAR][c];
-        } else {
-            const MmsPt p = mms_node<CASE>(m, f1.tm, tb, li, j);
-            fv = (VAR == VAR_T) ? mms_fT(m, p) : (VAR == VAR_CL) ? mms_fcl(m, p) : mms_fcd<REACT>(m, p);
-        }
-        double r;
-        if (VAR == VAR_T) {
-            const St5 T = load5(a.To, g, li, j);
-            r = a.YT[c] - (2.0 * T.c - dt * (fv + rhs_T(m, ge, T, a.cp1[c])));
-        } else if (VAR == VAR_CL) {
-            const St5 cp = load5(a.cp1, g, li, j), T = load5(a.To, g, li, j), cl = load5(a.clo, g, li, j);
-            const double F = fv + rhs_cl(m, ge, faces_Dl(m, cp), T, cl, cp.c);
-            // coupling  dt * (dFcl/dT) (Tn - To), boundary entries of (Tn - To) dropped
-            const int i = g.i0 + li;
-            const double w_ok = (i > 1) ? 1.0 : 0.0, e_ok = (i < g.N - 1) ? 1.0 : 0.0;
-            const Coef5 k = jac_T_Fcl(m, ge, cl, w_ok, e_ok);
-            const double ww = a.Tn[c - g.ld] - T.w, we = a.Tn[c + g.ld] - T.e;
-            r = a.Ycl[c] - 2.0 * cl.c + dt * F + dt * (k.e * we + k.w * ww);
-        } else {
-            const St5 cp = load5(a.cp1, g, li, j), T = load5(a.To, g, li, j), cd = load5(a.cdo, g, li, j);
-            const double clc = a.clo[c], csc = a.cs1[c];
-            const double F = fv + rhs_cd_diffusion(ge, faces_Dd(m, cp, T), cd) + reaction<REACT>(m, clc, cd.c, csc);
-            // coupling with (Tn - To) keeps the boundary entries of the increment
-            const Coef5 k = jac_T_Fcd(ge, faces_dDd_dT(m, cp, T), cd);
-            const St5 Tn = load5(a.Tn, g, li, j);
-            const double JTw = k.c * (Tn.c - T.c) + k.e * (Tn.e - T.e) + k.w * (Tn.w - T.w) + k.n * (Tn.n - T.n) +
-                               k.s * (Tn.s - T.s);
-            const double Jclw = jac_cl_Fcd_diag<REACT>(m, cd.c, csc) * (a.cln[c] - clc);
-            r = a.Ycd[c] - 2.0 * cd.c + dt * F + dt * JTw + dt * Jclw;
-        }
+        const double r = newton_rhs_value<VAR, CASE, REACT>(g, m, tb, f1, a, dt, li, j);
         double diag, oe, ow, on, os;
         newton_row<VAR, REACT>(m, g, a, li, j, dt, diag, oe, ow, on, os);
         rhs[c] = r;
         d1[c] = r / diag;
     }
+};
+
+// Arguments of one launch of the LDS-blocked Newton solve chain (kernel in tedd_blocked.hpp).
+struct BlockedArgs {
+    GridDev g;
+    ModelC m;
+    MmsTabs tb;
+    ForcingSrc f1;
+    NewtonIn a;
+    const double* rhs_in;
+    const double* d_in;
+    double* rhs_out;
+    double* d_out;
+    double* u_out;
+    double dt;
+    int r0, r1;      // output rows (local)
+    int H;           // halo depth of this launch
+    int nsweeps;     // sweeps performed by this launch (<= H)
+    int tiles_x;
+    unsigned long long* stats;
 };
 
 // K_jacobi: one matrix-free Jacobi sweep; coefficients are rebuilt from the lagged fields.

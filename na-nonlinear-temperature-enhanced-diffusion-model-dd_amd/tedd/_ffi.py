@@ -50,6 +50,7 @@ PROTOTYPES = {
     "tedd_destroy": (None, [C.c_void_p]),
     "tedd_last_error": (C.c_char_p, [C.c_void_p]),
     "tedd_set_model": (C.c_int, [C.c_void_p, _dptr, C.c_int32, C.c_double, _dptr]),
+    "tedd_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "tedd_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tedd_sync": (C.c_int, [C.c_void_p]),
     "tedd_local_rows": (C.c_int32, [C.c_void_p]),
@@ -195,6 +196,9 @@ class Context:
         params = list(mms_params) + [0.0] * (8 - len(mms_params))
         p = (C.c_double * 8)(*[float(v) for v in params])
         self._check(self._lib.tedd_set_model(self._h, c, model_kind, float(eta), p))
+
+    def set_option(self, name, value):
+        self._check(self._lib.tedd_set_option(self._h, name.encode(), float(value)))
 
     def set_stream(self, stream_handle):
         self._check(self._lib.tedd_set_stream(self._h, C.c_void_p(stream_handle)))

@@ -83,7 +83,7 @@ def check_mms(tag):
     return worst_exact, worst_forcing
 
 
-def run_steps(tag, **overrides):
+def run_steps(tag, options=None, **overrides):
     """Integrate a golden step fixture; returns (max state error relative to the field scale,
     max absolute residual error, stats of the last step)."""
     z = load("golden_steps.npz")
@@ -91,6 +91,8 @@ def run_steps(tag, **overrides):
     cname = str(z[f"{tag}/case"]) if f"{tag}/case" in z.files else tag.split("/")[1]
     rk = _ffi.REACT_REGHCSTRIPLE if kind.endswith("reg") else _ffi.REACT_CSTRIPLE
     ctx = make_ctx(z, tag, rk, CASE_ID[cname], CASE_PARAMS[cname])
+    for name, value in (options or {}).items():
+        ctx.set_option(name, value)
     ctx.set_state(*[z[f"{tag}/s0/{v}"] for v in VARS])
     t0, dt = float(z[f"{tag}/t0"]), float(z[f"{tag}/dt"])
     saved = sorted(int(k.split("/")[-2][1:]) for k in z.files

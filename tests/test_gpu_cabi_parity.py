@@ -34,9 +34,18 @@ def test_mms_exact_and_forcing(tag):
     assert e_forcing < 1e-13   # relative to the O(1) exact fields the forcing is a residual of
 
 
+# solver variants: one launch per Jacobi sweep; the LDS-blocked chain with its automatic depth;
+# the chain forced to 2 and 3 sweeps per launch (first / middle / last launches all exercised)
+SOLVERS = {"sweeps": {"blocked_solve": 0}, "blocked": {"blocked_solve": 1},
+           "blocked_h2": {"blocked_solve": 1, "blocked_hmax": 2}, "blocked_h3": {"blocked_solve": 1, "blocked_hmax": 3}}
+
+
+@pytest.mark.parametrize("solver", list(SOLVERS))
 @pytest.mark.parametrize("tag", cc.tags("golden_steps.npz", "/t0"))
-def test_integrator_steps(tag):
-    err, res_err, stats = cc.run_steps(tag)
+def test_integrator_steps(tag, solver):
+    if not tag.startswith("pc") and solver != "blocked":
+        pytest.skip("forward Euler has no linear solve")
+    err, res_err, stats = cc.run_steps(tag, options=SOLVERS[solver])
     # state after 1, 2 and 5 steps, relative to the largest field magnitude
     assert err < (2e-12 if "bigdt" in tag else 5e-14), (tag, err, stats)
     # Newton residuals: absolute (they are differences of O(1) quantities)
