@@ -34,18 +34,47 @@ NB_A = dict(R0=8.3144621, Ea=1.60217662e-19, K1=1e-3, K2=1e-3, K3=1e-3, K4=1e-3,
             Dl_max=1e-5, phi_l=1e-5, gamma_T=1e-9, Kd=1e-2, Sd=1, Dd_max=1e-6, phi_d=1e-5,
             phi_T=1.60217662e-19 / 8.3144621, r_sp=5e-2, T_ref=300)
 
-# distinct full-grid arrays read + written per launch of each kernel family (algorithmic traffic,
-# 8 bytes per node per array; halos and 1-D tables ignored)
-ARRAYS_PER_LAUNCH = {
-    "predict": 12,    # reads cp,T,cl,cd,cs + cached cell-averaged fcp(t0); writes Y_T,Y_cl,Y_cd,cp*,cs*,fcp(t1)
-    "rhs_T": 5,       # reads cp*, T, Y_T; writes rhs, delta_1
-    "rhs_cl": 7,      # reads cp*, T, T_new, cl, Y_cl; writes rhs, delta_1
-    "rhs_cd": 10,     # reads cp*, cs*, T, T_new, cl, cl_new, cd, Y_cd; writes rhs, delta_1
-    "jacobi_T": 4,    # reads delta, rhs, cp*; writes delta (final sweep: +T, writes T_new)
-    "jacobi_cl": 5,   # reads delta, rhs, cp*, T; writes delta
-    "jacobi_cd": 7,   # reads delta, rhs, cp*, T, cl, cs*; writes delta
-    "cs_newton": 12,  # reads cp,T,cl,cd,cs, T_new,cl_new,cd_new, fcp(t0), fcp(t1); writes cp_new, cs_new
-}
+# Distinct full-grid arrays read + written per launch of each kernel family (algorithmic traffic:
+# 8 bytes per node per array; stencil neighbours, tile halos and 1-D tables not counted).
+def arrays_per_launch(solver, cache_forcing, sweeps, hmax):
+    """-> ({family: arrays per launch (chain families: average over the chain's launches)},
+           {chain family: {"launches_per_solve", "arrays_per_solve"}})"""
+    a = {}
+    if cache_forcing:
+        a["forcing"] = 5        # writes fcp (cell averages), fT, fcl, fcd, fcs of the new time level
+        a["predict"] = 17       # reads cp,T,cl,cd,cs, the 5 forcing arrays at t0, fcp and fcs at t1; writes Y_T,Y_cl,Y_cd,cp*,cs*
+        a["cs_newton"] = 14     # reads cp,T,cl,cd,cs, T_new,cl_new,cd_new, fcp and fcs at t0 and t1; writes cp_new, cs_new
+        f = 1                   # the forcing array each rhs kernel reads
+    else:
+        a["predict"] = 12       # reads cp,T,cl,cd,cs + cached fcp(t0); writes Y_T,Y_cl,Y_cd,cp*,cs*,fcp(t1)
+        a["cs_newton"] = 12     # reads cp,T,cl,cd,cs, T_new,cl_new,cd_new, fcp(t0), fcp(t1); writes cp_new, cs_new
+        f = 0
+    w = 1 if solver == "strip" else 2           # strip: writes b = rhs/diag; others: rhs and delta_1
+    a["rhs_T"] = 3 + f + w      # reads cp*, T, Y_T
+    a["rhs_cl"] = 5 + f + w     # reads cp*, T, T_new, cl, Y_cl
+    a["rhs_cd"] = 8 + f + w     # reads cp*, cs*, T, T_new, cl, cl_new, cd, Y_cd
+    a["jacobi_T"] = 4           # reads delta, rhs, cp*; writes delta (final sweep: +T, writes T_new)
+    a["jacobi_cl"] = 5          # reads delta, rhs, cp*, T; writes delta
+    a["jacobi_cd"] = 7          # reads delta, rhs, cp*, T, cl, cs*; writes delta
+    chains = {}
+    coef = {"T": 1, "cl": 2, "cd": 4}           # coefficient fields of the rows: cp* | cp*,T | cp*,T,cl,cs*
+    for k, var in enumerate(("T", "cl", "cd")):
+        L = max(1, -(-(sweeps[k] - 1) // hmax))
+        if solver == "strip":
+            # every launch reads b and the coefficient fields and writes one array; launches after the
+            # first also read the iterate; the last also reads the lagged unknown
+            arr = sum(1 + coef[var] + (1 if l > 0 else 0) + (1 if l == L - 1 else 0) + 1 for l in range(L))
+        elif solver == "blocked":
+            single = {"T": 4, "cl": 6, "cd": 9}[var]
+            first = {"T": 5, "cl": 7, "cd": 10}[var]
+            middle = {"T": 4, "cl": 5, "cd": 7}[var]
+            last = {"T": 5, "cl": 6, "cd": 8}[var]
+            arr = single if L == 1 else first + (L - 2) * middle + last
+        else:
+            continue
+        chains["solve_" + var] = {"launches_per_solve": L, "arrays_per_solve": arr}
+        a["solve_" + var] = arr / L
+    return a, chains
 
 
 def consts_vec(d):
@@ -112,6 +141,12 @@ def main():
     ap.add_argument("--mesh", type=int, default=16384, help="N of the (N+1)^2-node synthetic mesh")
     ap.add_argument("--jacobi-tol", type=float, default=1e-13)
     ap.add_argument("--no-extras", action="store_true", help="skip the N=256 study-mesh and CPU-baseline legs")
+    ap.add_argument("--solver", choices=["strip", "blocked", "sweeps"], default="strip",
+                    help="Newton solve: register-resident chain | LDS-blocked chain | one launch per Jacobi sweep")
+    ap.add_argument("--hmax", type=int, default=8, help="Jacobi sweeps fused per launch of a solve chain")
+    ap.add_argument("--cache-forcing", type=int, default=1,
+                    help="1: forcing arrays evaluated once per time level; 0: inside the step kernels")
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value (repeatable)")
     args = ap.parse_args()
 
     import torch
@@ -140,6 +175,12 @@ def main():
                        mms_case=_ffi.MMS_EXPSIN, row_lo=slab.row_lo, row_hi=slab.row_hi, ghost=slab.ghost,
                        device=local_rank)
     stepper = SlabStepper(ctx, slab, device)
+    ctx.set_option("blocked_solve", {"strip": 2, "blocked": 1, "sweeps": 0}[args.solver])
+    ctx.set_option("cache_forcing", args.cache_forcing)
+    ctx.set_option("blocked_hmax", args.hmax)
+    for kv in args.opt:
+        name, value = kv.split("=")
+        ctx.set_option(name, float(value))
     ctx.set_state_exact(0.0)
     kw = dict(jacobi_sweeps=sweeps, jacobi_tol=args.jacobi_tol)
 
@@ -178,24 +219,24 @@ def main():
     err_H = float(np.sqrt(np.sum(norms[:5])))
 
     n_nodes_local = (slab.row_hi - slab.row_lo) * (N + 1)
+    arrays, chains = arrays_per_launch(args.solver, args.cache_forcing, sweeps, args.hmax)
+
+    def gbps(fam):
+        per_launch_s = prof[fam]["total_ms"] / prof[fam]["launches"] * 1e-3
+        return 8.0 * n_nodes_local * arrays.get(fam, 0) / per_launch_s / 1e9
+
     fam = max(prof, key=lambda k: prof[k]["total_ms"]) if prof else None
     roofline = None
     if fam is not None:
         per_launch_ms = prof[fam]["total_ms"] / prof[fam]["launches"]
-        bytes_per_launch = 8.0 * n_nodes_local * ARRAYS_PER_LAUNCH.get(fam, 0)
-        achieved = bytes_per_launch / (per_launch_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": fam, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "arrays_per_launch": ARRAYS_PER_LAUNCH.get(fam, 0), "avg_launch_ms": per_launch_ms,
+        roofline = {"bound": "hbm", "kernel": fam, "achieved": gbps(fam), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbps(fam) / HBM_PEAK_GBS, "traffic": None,
+                    "arrays_per_launch": arrays.get(fam, 0), "avg_launch_ms": per_launch_ms,
                     "launches": prof[fam]["launches"], "nodes_per_launch": n_nodes_local}
     kernels = {k: {"launches": v["launches"], "avg_ms": v["total_ms"] / v["launches"],
-                   "share": v["total_ms"] / (1e3 * elapsed),
-                   "GBps": 8.0 * n_nodes_local * ARRAYS_PER_LAUNCH.get(k, 0) / (v["total_ms"] / v["launches"] * 1e-3) / 1e9}
-               for k, v in prof.items()}
-    arrays_step = (ARRAYS_PER_LAUNCH["predict"] + ARRAYS_PER_LAUNCH["rhs_T"] + ARRAYS_PER_LAUNCH["rhs_cl"]
-                   + ARRAYS_PER_LAUNCH["rhs_cd"] + ARRAYS_PER_LAUNCH["cs_newton"]
-                   + (sweeps[0] - 1) * ARRAYS_PER_LAUNCH["jacobi_T"] + (sweeps[1] - 1) * ARRAYS_PER_LAUNCH["jacobi_cl"]
-                   + (sweeps[2] - 1) * ARRAYS_PER_LAUNCH["jacobi_cd"])
+                   "share": v["total_ms"] / (1e3 * elapsed), "GBps": gbps(k)} for k, v in prof.items()}
+    # arrays per step = sum over the launches the step actually made
+    arrays_step = sum(arrays.get(k, 0) * v["launches"] for k, v in prof.items()) / args.steps
     step_gbs = 8.0 * (N + 1) * (N + 1) * arrays_step * args.steps / elapsed / 1e9
 
     out = {
@@ -206,6 +247,8 @@ def main():
         "config": {"workload": f"MMSCaseExpSin reghcstriple, {N}x{N}-cell mesh ({(N + 1) ** 2} nodes), dt=h^1.5, "
                                f"eta=50, notebook model constants, 1 PC x 1 Newton step, 5 cs-Newton iterations",
                    "mesh_N": N, "jacobi_sweeps": sweeps, "jacobi_tol": args.jacobi_tol,
+                   "solver": args.solver, "sweeps_per_launch": args.hmax, "solve_chains": chains,
+                   "forcing": "arrays per time level" if args.cache_forcing else "closed form inside the step kernels",
                    "parallelism": f"row slabs x{world}, ghost={slab.ghost}", "error_H_after_run": err_H},
         "roofline": roofline,
         "step_hbm": {"algorithmic_arrays_per_step": arrays_step, "achieved_GBps_all_gpus": step_gbs,

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) k_solve_blocked(const BlockedArgs A) {
                 rv = A.rhs_in[c];
             double diag, oe, ow, on, os;
             newton_row<VAR, REACT>(A.m, g, A.a, li, j, A.dt, diag, oe, ow, on, os);
-            const double inv = 1.0 / diag;
+            const double inv = tedd_div(1.0, diag);
             bb = rv * inv;
             e = oe * inv;
             w = ow * inv;

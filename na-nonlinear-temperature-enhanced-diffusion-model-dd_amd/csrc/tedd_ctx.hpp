@@ -35,12 +35,12 @@ struct NotConverged : std::runtime_error {
 enum Fam : int {
     FAM_PREDICT = 0, FAM_RHS_T, FAM_RHS_CL, FAM_RHS_CD, FAM_JACOBI_T, FAM_JACOBI_CL, FAM_JACOBI_CD,
     FAM_CORRECT, FAM_CS_NEWTON, FAM_FIELD, FAM_RESIDUAL, FAM_NORMS, FAM_MISC, FAM_SOLVE_T, FAM_SOLVE_CL,
-    FAM_SOLVE_CD, FAM_COUNT
+    FAM_SOLVE_CD, FAM_FORCING, FAM_COUNT
 };
 inline const char* fam_name(int f) {
     static const char* n[FAM_COUNT] = {"predict", "rhs_T", "rhs_cl", "rhs_cd", "jacobi_T", "jacobi_cl",
                                        "jacobi_cd", "correct", "cs_newton", "field", "residual", "norms",
-                                       "misc", "solve_T", "solve_cl", "solve_cd"};
+                                       "misc", "solve_T", "solve_cl", "solve_cd", "forcing"};
     return n[f];
 }
 
@@ -95,6 +95,12 @@ public:
     // cp-forcing cell-average cache: fcp_buf[k] holds the array at time fcp_time[k]
     double fcp_time[2] = {NAN, NAN};
     bool stream_forcing_set[2] = {false, false};
+    // forcing cache (closed-form cases): the five forcing arrays of a time level are evaluated
+    // once by ForcingFn and the step kernels read them like streamed forcing
+    int opt_cache_forcing = 1;
+    int fset[2] = {0, 1};            // which physical array set serves time level 0 / 1
+    double fset_time[2] = {NAN, NAN};
+    bool forcing_from_cache = false;
 
     Ctx(const tedd_config& c, const double* x, const double* y) : cfg(c) {
         N = c.N;
@@ -172,6 +178,7 @@ public:
         }
         if (params_changed && d_bx) build_mms_tables();
         fcp_time[0] = fcp_time[1] = NAN;  // cached forcing depends on the constants
+        fset_time[0] = fset_time[1] = NAN;
         last.have = false;
     }
 
@@ -261,7 +268,9 @@ public:
         ForcingSrc s;
         s.tm = mms_time_fill(mms_case, model, mp, t);
         for (int v = 0; v < 5; ++v) s.f[v] = nullptr;
-        if (mms_case == CASE_STREAM) {
+        if (forcing_from_cache) {
+            for (int v = 0; v < 5; ++v) s.f[v] = slot[(fset[which] ? SF10 : SF00) + v];
+        } else if (mms_case == CASE_STREAM) {
             if (!stream_forcing_set[which]) throw InvalidError("streamed forcing not set for this time level");
             for (int v = 0; v < 5; ++v) s.f[v] = slot[(which ? SF10 : SF00) + v];
         }
@@ -385,8 +394,8 @@ public:
 
     // ------------------------------------------------------------------ dispatch helpers
     template <class Fn>
-    void dispatch(Fn&& fn) {
-        const int c = mms_case, r = react;
+    void dispatch(Fn&& fn, int case_override = -100) {
+        const int c = (case_override == -100) ? mms_case : case_override, r = react;
 #define TEDD_D(CC, RR)             \
     if (c == CC && r == RR) {      \
         fn.template run<CC, RR>(); \
@@ -508,8 +517,11 @@ public:
             if (CASE == CASE_STREAM) throw InvalidError("forcing is streamed: nothing to evaluate");
             Out5 o;
             for (int v = 0; v < 5; ++v) o.v[v] = out[v];
-            ForcingFn<(CASE == CASE_STREAM ? CASE_POL : CASE), REACT> f{C.grid(), C.model, C.tabs(), C.forcing_src(t, 0), o};
-            C.be.nodes(FAM_MISC, f, 0, C.nrows, C.ncols);
+            ForcingSrc src;
+            src.tm = mms_time_fill(C.mms_case, C.model, C.mp, t);
+            for (int v = 0; v < 5; ++v) src.f[v] = nullptr;
+            ForcingFn<(CASE == CASE_STREAM ? CASE_POL : CASE), REACT> f{C.grid(), C.model, C.tabs(), src, o};
+            C.be.nodes(FAM_FORCING, f, 0, C.nrows, C.ncols);
         }
     };
     void eval_forcing(double t, double* const h[5]) {
@@ -623,7 +635,37 @@ public:
             p.sweeps[v] = (s > 0) ? std::max(2, (int)s) : auto_sweeps(dt * std::fabs(dcoef[v]) * q_metric, jtol, jmax);
         }
         PcOp op{this, p};
+        if (opt_cache_forcing && mms_case != CASE_STREAM) {
+            // evaluate the closed-form forcing once per time level, then run the array-fed kernels
+            int k0 = -1;
+            for (int k = 0; k < 2; ++k)
+                if (fset_time[k] == t0) k0 = k;
+            if (k0 < 0) {
+                k0 = 0;
+                fill_forcing_set(t0, k0);
+            }
+            const int k1 = 1 - k0;
+            fill_forcing_set(t0 + dt, k1);
+            fset[0] = k0;
+            fset[1] = k1;
+            forcing_from_cache = true;
+            try {
+                dispatch(op, CASE_STREAM);
+            } catch (...) {
+                forcing_from_cache = false;
+                throw;
+            }
+            forcing_from_cache = false;
+            return;
+        }
         dispatch(op);
+    }
+    void fill_forcing_set(double t, int k) {
+        ForcingOp op{this, t, {B((k ? SF10 : SF00)), B((k ? SF10 : SF00) + 1), B((k ? SF10 : SF00) + 2),
+                               B((k ? SF10 : SF00) + 3), B((k ? SF10 : SF00) + 4)}};
+        dispatch(op);
+        for (int v = 0; v < 5; ++v) mark(op.out[v], full());
+        fset_time[k] = t;
     }
 
     // valid range of a launch that reads `uses` with a halo of `depth` rows (+1 where stencil)
@@ -641,17 +683,19 @@ public:
     }
 
     // options
-    int opt_blocked = 1;      // use the LDS-blocked solve where the backend has it
+    int opt_blocked = 2;      // 0: one launch per sweep; 1: LDS-blocked chain; 2: register-resident chain (backends that have them)
     int opt_hmax = 0;         // sweeps fused per launch (0 = automatic)
+    int opt_fuse_rhs[3] = {1, 1, 1};  // per system (T, cl, cd): compute the rhs inside the first blocked launch
 
     template <int VAR, int CASE, int REACT>
     void newton_solve_blocked(const StepParams& p, const ForcingSrc& f1, const NewtonIn& a, double* unew, int nsweeps,
                               int slot_id) {
         if constexpr (Backend::kHasBlockedSolve) {
             const int fam = (VAR == VAR_T) ? FAM_SOLVE_T : (VAR == VAR_CL) ? FAM_SOLVE_CL : FAM_SOLVE_CD;
-            int remaining = nsweeps - 1;  // the first launch also produces delta^1
+            int remaining = nsweeps - 1;  // delta^1 = rhs/diag comes with the right-hand side
             int hmax = opt_hmax > 0 ? opt_hmax : ((size_t)nrows * ncols > (size_t)1 << 20 ? 8 : 12);
             hmax = std::min(hmax, 24);
+            const bool fuse = opt_fuse_rhs[slot_id] != 0;
             const int L = std::max(1, (remaining + hmax - 1) / hmax);
             BlockedArgs A;
             A.g = grid();
@@ -662,13 +706,32 @@ public:
             A.dt = p.dt;
             A.stats = reinterpret_cast<unsigned long long*>(d_red + 2 * slot_id);
             A.tiles_x = 0;
-            double* rhs = (L > 1) ? B(RHS) : nullptr;
-            double* dbuf[2] = {L > 1 ? B(DA) : nullptr, L > 2 ? B(DB) : nullptr};
+            double* rhs = (L > 1 || !fuse) ? B(RHS) : nullptr;
+            double* dbuf[2] = {(L > 1 || !fuse) ? B(DA) : nullptr, (L > 2 || (!fuse && L > 1)) ? B(DB) : nullptr};
             const double* din = nullptr;
+            int dsel = 0;
+            if (!fuse) {
+                // right-hand side and delta^1 by the one-thread-per-node kernel (high occupancy)
+                Range r;
+                if (VAR == VAR_T)
+                    r = need({{a.cp1, false}, {a.To, true}, {a.YT, false}});
+                else if (VAR == VAR_CL)
+                    r = need({{a.cp1, true}, {a.To, true}, {a.clo, true}, {a.Tn, true}, {a.Ycl, false}});
+                else
+                    r = need({{a.cp1, true}, {a.To, true}, {a.cdo, true}, {a.clo, false}, {a.cs1, false}, {a.Tn, true},
+                              {a.cln, false}, {a.Ycd, false}});
+                const int fam_rhs = (VAR == VAR_T) ? FAM_RHS_T : (VAR == VAR_CL) ? FAM_RHS_CL : FAM_RHS_CD;
+                NewtonRhsFn<VAR, CASE, REACT> fr{A.g, model, A.tb, f1, a, rhs, dbuf[0], p.dt};
+                be.nodes(fam_rhs, fr, r.lo, r.hi, ncols);
+                mark(rhs, r);
+                mark(dbuf[0], r);
+                din = dbuf[0];
+                dsel = 1;
+            }
             for (int l = 0; l < L; ++l) {
                 const int ns = (remaining + (L - l) - 1) / (L - l);
                 remaining -= ns;
-                const bool first = (l == 0), lastl = (l == L - 1);
+                const bool first = (l == 0) && fuse, lastl = (l == L - 1);
                 A.H = ns;
                 A.nsweeps = ns;
                 Range r;
@@ -694,7 +757,7 @@ public:
                 A.rhs_in = first ? nullptr : rhs;
                 A.d_in = din;
                 A.rhs_out = (first && !lastl) ? rhs : nullptr;
-                double* dout = lastl ? nullptr : dbuf[l & 1];
+                double* dout = lastl ? nullptr : dbuf[(l + dsel) & 1];
                 A.d_out = dout;
                 A.u_out = lastl ? unew : nullptr;
                 if (first && lastl)
@@ -715,9 +778,81 @@ public:
         }
     }
 
+    // Register-resident solve chain (tedd_strip.hpp): b = delta^1 = rhs/diag from the node kernel,
+    // then ceil((nsweeps-1)/hmax) launches that iterate on (b, delta).
+    template <int VAR, int CASE, int REACT>
+    void newton_solve_strip(const StepParams& p, const ForcingSrc& f1, const NewtonIn& a, double* unew, int nsweeps,
+                            int slot_id) {
+        if constexpr (Backend::kHasBlockedSolve) {
+            const int fam = (VAR == VAR_T) ? FAM_SOLVE_T : (VAR == VAR_CL) ? FAM_SOLVE_CL : FAM_SOLVE_CD;
+            const int fam_rhs = (VAR == VAR_T) ? FAM_RHS_T : (VAR == VAR_CL) ? FAM_RHS_CL : FAM_RHS_CD;
+            int remaining = nsweeps - 1;
+            int hmax = opt_hmax > 0 ? opt_hmax : 8;
+            hmax = std::min(hmax, 16);
+            const int L = std::max(1, (remaining + hmax - 1) / hmax);
+            BlockedArgs A;
+            A.g = grid();
+            A.m = model;
+            A.tb = tabs();
+            A.f1 = f1;
+            A.a = a;
+            A.dt = p.dt;
+            A.stats = reinterpret_cast<unsigned long long*>(d_red + 2 * slot_id);
+            A.tiles_x = 0;
+            A.rhs_out = nullptr;
+            double* bsc = B(DA);
+            double* iter[2] = {B(DB), B(RHS)};
+            Range r;
+            if (VAR == VAR_T)
+                r = need({{a.cp1, false}, {a.To, true}, {a.YT, false}});
+            else if (VAR == VAR_CL)
+                r = need({{a.cp1, true}, {a.To, true}, {a.clo, true}, {a.Tn, true}, {a.Ycl, false}});
+            else
+                r = need({{a.cp1, true}, {a.To, true}, {a.cdo, true}, {a.clo, false}, {a.cs1, false}, {a.Tn, true},
+                          {a.cln, false}, {a.Ycd, false}});
+            NewtonRhsFn<VAR, CASE, REACT> fr{A.g, model, A.tb, f1, a, nullptr, bsc, p.dt};
+            be.nodes(fam_rhs, fr, r.lo, r.hi, ncols);
+            mark(bsc, r);
+            const double* din = bsc;
+            for (int l = 0; l < L; ++l) {
+                const int ns = (remaining + (L - l) - 1) / (L - l);
+                remaining -= ns;
+                const bool lastl = (l == L - 1);
+                A.H = ns;
+                A.nsweeps = ns;
+                if (VAR == VAR_T)
+                    r = need_depth({{a.cp1, false}, {bsc, false}, {din, false}}, ns);
+                else if (VAR == VAR_CL)
+                    r = need_depth({{a.cp1, true}, {a.To, true}, {bsc, false}, {din, false}}, ns);
+                else
+                    r = need_depth({{a.cp1, true}, {a.To, true}, {a.clo, false}, {a.cs1, false}, {bsc, false},
+                                    {din, false}}, ns);
+                A.r0 = r.lo;
+                A.r1 = r.hi;
+                A.rhs_in = bsc;
+                A.d_in = din;
+                double* dout = lastl ? nullptr : iter[l & 1];
+                A.d_out = dout;
+                A.u_out = lastl ? unew : nullptr;
+                if (lastl) {
+                    be.template solve_strip<VAR, REACT, true>(fam, A, ncols);
+                    mark(unew, r);
+                } else {
+                    be.template solve_strip<VAR, REACT, false>(fam, A, ncols);
+                    mark(dout, r);
+                }
+                din = dout;
+            }
+        }
+    }
+
     template <int VAR, int CASE, int REACT>
     void newton_solve(const StepParams& p, const ForcingSrc& f1, const NewtonIn& a, double* unew, int nsweeps, int slot_id) {
         if constexpr (Backend::kHasBlockedSolve) {
+            if (opt_blocked == 2) {
+                newton_solve_strip<VAR, CASE, REACT>(p, f1, a, unew, nsweeps, slot_id);
+                return;
+            }
             if (opt_blocked) {
                 newton_solve_blocked<VAR, CASE, REACT>(p, f1, a, unew, nsweeps, slot_id);
                 return;
@@ -923,9 +1058,17 @@ public:
 
     void set_option(const std::string& name, double value) {
         if (name == "blocked_solve")
-            opt_blocked = value != 0.0;
+            opt_blocked = (int)value;
         else if (name == "blocked_hmax")
             opt_hmax = (int)value;
+        else if (name == "cache_forcing")
+            opt_cache_forcing = value != 0.0;
+        else if (name == "fuse_rhs_T")
+            opt_fuse_rhs[0] = value != 0.0;
+        else if (name == "fuse_rhs_cl")
+            opt_fuse_rhs[1] = value != 0.0;
+        else if (name == "fuse_rhs_cd")
+            opt_fuse_rhs[2] = value != 0.0;
         else
             throw InvalidError("unknown option: " + name);
     }

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "tedd_blocked.hpp"
+#include "tedd_strip.hpp"
 #include "tedd_ctx.hpp"
 
 namespace tedd {
@@ -141,6 +142,15 @@ __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_R
         }
         __syncthreads();
     }
+    // per-thread record of the first kCsReg iterations (the usual case: 5), reduced once at the end
+    constexpr int kCsReg = 8;
+    const bool in_regs = (iters <= kCsReg);
+    double rmx[kCsReg], rmn[kCsReg];
+#pragma unroll
+    for (int k = 0; k < kCsReg; ++k) {
+        rmx[k] = 0.0;
+        rmn[k] = INFINITY;
+    }
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int j = (t % tiles_x) * kTileX + threadIdx.x;
         const int li = r0 + (t / tiles_x) * kTileY + threadIdx.y;
@@ -154,25 +164,52 @@ __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_R
             if (record) cp_out[c] = corrector_cp(a, li, j);
             cs_newton_inputs(a, li, j, y, av, x);
         }
-        for (int k = 0; k < keep; ++k) {
-            double adx = 0.0, ax = INFINITY;
-            if (active) {
-                const double dx = cs_newton_step(x, y, av, a.m.eta);
-                x = x + dx;
-                adx = fabs(dx);
-                ax = fabs(x);
-                if (adx != adx) adx = INFINITY;
-                if (ax != ax) ax = 0.0;
+        if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < kCsReg; ++k) {
+                if (k < keep && active) {
+                    const double dx = cs_newton_step(x, y, av, a.m.eta);
+                    x = x + dx;
+                    double adx = fabs(dx), ax = fabs(x);
+                    if (adx != adx) adx = INFINITY;
+                    if (ax != ax) ax = 0.0;
+                    rmx[k] = adx > rmx[k] ? adx : rmx[k];
+                    rmn[k] = ax < rmn[k] ? ax : rmn[k];
+                }
             }
-            if (record) {
-                const double wmx = wave_max(adx), wmn = wave_min(ax);
+        } else {
+            for (int k = 0; k < keep; ++k) {
+                double adx = 0.0, ax = INFINITY;
+                if (active) {
+                    const double dx = cs_newton_step(x, y, av, a.m.eta);
+                    x = x + dx;
+                    adx = fabs(dx);
+                    ax = fabs(x);
+                    if (adx != adx) adx = INFINITY;
+                    if (ax != ax) ax = 0.0;
+                }
+                if (record) {
+                    const double wmx = wave_max(adx), wmn = wave_min(ax);
+                    if (threadIdx.x == 0) {
+                        atomicMax(&sm[k], (unsigned long long)__double_as_longlong(wmx));
+                        atomicMin(&sm[iters + k], (unsigned long long)__double_as_longlong(wmn));
+                    }
+                }
+            }
+        }
+        if (active) cs_out[c] = in ? x : 0.0 * x;
+    }
+    if (record && in_regs) {
+#pragma unroll
+        for (int k = 0; k < kCsReg; ++k) {
+            if (k < iters) {
+                const double wmx = wave_max(rmx[k]), wmn = wave_min(rmn[k]);
                 if (threadIdx.x == 0) {
                     atomicMax(&sm[k], (unsigned long long)__double_as_longlong(wmx));
                     atomicMin(&sm[iters + k], (unsigned long long)__double_as_longlong(wmn));
                 }
             }
         }
-        if (active) cs_out[c] = in ? x : 0.0 * x;
     }
     if (record) {
         __syncthreads();
@@ -390,6 +427,21 @@ struct HipBackend {
         const long long nt = (long long)A.tiles_x * ((A.r1 - A.r0 + TI - 1) / TI);
         if (nt > 0x7fffffffLL) throw std::runtime_error("mesh too large for the tile index");
         hipLaunchKernelGGL((k_solve_blocked<VAR, CASE, REACT, FIRST, LAST>), dim3((unsigned)nt), dim3(kTileX, kTileY), 0,
+                           stream, A);
+        TEDD_HIP(hipGetLastError());
+    }
+    // one launch of the register-resident Newton solve chain (tedd_strip.hpp)
+    template <int VAR, int REACT, bool LAST>
+    void solve_strip(int fam, BlockedArgs A, int ncols) {
+        if (A.r1 <= A.r0) return;
+        if (A.H < 0 || A.H > 16 || A.nsweeps < 0 || A.nsweeps > A.H) throw std::runtime_error("bad strip-solve depth");
+        if (A.rhs_in == nullptr || A.d_in == nullptr) throw std::runtime_error("strip solve needs rhs and delta^1");
+        Scope sc(this, fam);
+        const int TIR = kSTile - 2 * A.H, TIC = kSTile - 2 * strip_col_halo(A.H);
+        A.tiles_x = (ncols + TIC - 1) / TIC;
+        const long long nt = (long long)A.tiles_x * ((A.r1 - A.r0 + TIR - 1) / TIR);
+        if (nt > 0x7fffffffLL) throw std::runtime_error("mesh too large for the tile index");
+        hipLaunchKernelGGL((k_solve_strip<VAR, REACT, LAST>), dim3((unsigned)nt), dim3(kSTile, StripShape<VAR>::W), 0,
                            stream, A);
         TEDD_HIP(hipGetLastError());
     }

@@ -288,15 +288,15 @@ struct NewtonRhsFn {
     TEDD_HD void operator()(int li, int j) const {
         const size_t c = at(g, li, j);
         if (!is_interior(g, li, j)) {
-            rhs[c] = 0.0;
+            if (rhs) rhs[c] = 0.0;
             d1[c] = 0.0;
             return;
         }
         const double r = newton_rhs_value<VAR, CASE, REACT>(g, m, tb, f1, a, dt, li, j);
         double diag, oe, ow, on, os;
         newton_row<VAR, REACT>(m, g, a, li, j, dt, diag, oe, ow, on, os);
-        rhs[c] = r;
-        d1[c] = r / diag;
+        if (rhs) rhs[c] = r;  // not needed by solvers that iterate on rhs/diag
+        d1[c] = tedd_div(r, diag);
     }
 };
 
@@ -347,7 +347,7 @@ struct JacobiFn {
         double diag, oe, ow, on, os;
         newton_row<VAR, REACT>(m, g, a, li, j, dt, diag, oe, ow, on, os);
         const double dn =
-            (rhs[c] + oe * din[c + g.ld] + ow * din[c - g.ld] + on * din[c + 1] + os * din[c - 1]) / diag;
+            tedd_div(rhs[c] + oe * din[c + g.ld] + ow * din[c - g.ld] + on * din[c + 1] + os * din[c - 1], diag);
         if (FINAL) {
             out[c] = uo[c] + dn;
             const double up = fabs(dn - din[c]), mag = fabs(dn);
@@ -439,7 +439,7 @@ TEDD_HD double corrector_cp(const CorrectIn<CASE, REACT>& a, int li, int j) {
     const double al0 = -m.K2 * a.S0.v[VAR_T][c] - m.K1 * (a.S0.v[VAR_CL][c] + 1.0);
     const double al1 = -m.K2 * a.T1[c] - m.K1 * (a.cl1[c] + 1.0);
     const double num = (1.0 + h * al0) * a.S0.v[VAR_CP][c] + h * (s0 + s1);
-    return num / (1.0 - h * al1);
+    return tedd_div(num, 1.0 - h * al1);
 }
 
 template <int CASE, int REACT>
@@ -465,7 +465,7 @@ TEDD_HD double corrector_cs_closed_form(const CorrectIn<CASE, REACT>& a, int li,
     const double b0 = -m.Kd * (m.Sd - a.S0.v[VAR_CD][c]) * (1.0 + a.S0.v[VAR_CL][c]);
     const double b1 = -m.Kd * (m.Sd - a.cd1[c]) * (1.0 + a.cl1[c]);
     const double num = (1.0 + h * b0) * a.S0.v[VAR_CS][c] + h * (s0 + s1);
-    return num / (1.0 - h * b1);
+    return tedd_div(num, 1.0 - h * b1);
 }
 
 // y and a of  2x + (2x - y) e^{-eta x} = y - a   (all nodes, boundary included)
@@ -485,7 +485,7 @@ TEDD_HD double cs_newton_step(double x, double y, double av, double eta) {
     const double ex = exp(-eta * x);
     const double f = 2.0 * x + (2.0 * x - y) * ex - y + av;
     const double J = 2.0 + 2.0 * ex - eta * (2.0 * x - y) * ex;
-    return -f / J;
+    return tedd_div(-f, J);
 }
 
 // ------------------------------------------------------------------------------------

@@ -1,0 +1,320 @@
+// Register-resident Newton solve for gfx950: the stencil rows and up to H Jacobi sweeps of one
+// 5-diagonal system (2 I - dt J_v) delta = rhs_v in ONE launch, with the iterate kept in VGPRs.
+//
+// A workgroup owns a 64 x 64 tile of nodes.  Lanes map to consecutive columns j; each wave owns a
+// strip of R consecutive rows, so a thread holds an R-node column segment: the iterate delta[R] and
+// the scaled matrix row (b, ce, cw, cn, cs)[R] with b = rhs/diag and c* = (dt J_*)/diag.  One sweep
+// delta_c <- b + ce*delta_e + cw*delta_w + cn*delta_n + cs*delta_s  takes the row neighbours
+// (i -/+ 1) from the thread's own registers, the column neighbours (j -/+ 1) from the adjacent
+// lanes with DPP wave shifts (no LDS traffic), and only the two seam rows of every strip cross
+// waves through a few KB of LDS and one barrier per sweep.
+//
+// The T system (constant conductivity: off-diagonals depend on the mesh only) keeps just b and
+// 1/diag per node (<= 128 VGPRs, 4 tiles in flight per CU; the per-row off-diagonals are read from
+// LDS as broadcasts); the cl and cd systems
+// keep the full scaled row (<= 256 VGPRs, 2 tiles in flight per CU).
+//
+// Every node of the tile is updated in every sweep, with zeros standing in for the neighbours
+// outside the tile, so each sweep spoils one more ring of the tile: after s sweeps the nodes at
+// distance >= s from the tile edge hold exactly the s-th global Jacobi iterate (their dependency
+// cone lies inside the tile) and only the (64-2H)^2 interior is written back.  All global loads of the set-up are unconditional (clamped coordinates, results masked) so
+// that they are issued back to back instead of one dependent round trip per node, and every face
+// coefficient is evaluated once and shared with the neighbouring node (registers for the x faces,
+// a lane shift for the y faces).
+//
+// Launch chain for S sweeps: b = delta^1 = rhs/diag comes from NewtonRhsFn; each launch reloads
+// (b, delta) and continues; LAST adds delta to the lagged unknown, applies the
+// boundary rule and records max|delta^S - delta^(S-1)|, max|delta^S|.
+//
+// Replaces reference src/prob1base.py:2998-3115 (Newton steps incl. assembly :601-710 and
+// spsolve :2088-2130).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "tedd_nodes.hpp"
+
+namespace tedd {
+
+constexpr int kSTile = 64;  // tile edge (nodes), halo included
+
+template <int VAR>
+struct StripShape {
+    static constexpr int R = 16;                        // rows per thread
+    static constexpr int W = kSTile / R;                // waves per workgroup
+    static constexpr int OCC = (VAR == VAR_T) ? 4 : 2;  // waves per SIMD the register budget is set for
+    static constexpr int OCC_LAST = (VAR == VAR_T) ? 3 : 2;  // the launch that also keeps the record
+};
+
+// column halo of a launch of depth H: a multiple of 8 nodes, so that the 64-node row segments a
+// wave reads and the interior it writes start and end on 64-byte lines
+__host__ __device__ inline int strip_col_halo(int H) { return (H + 7) & ~7; }
+
+// 1/x without branches: hardware estimate, two Newton steps and a final residual correction
+// (<= 1 ulp for normal x of moderate magnitude; a zero, huge or tiny x gives inf/NaN, which the
+// convergence record of the solve then reports).  The diagonals 2 - dt J_c it is used on are >= 2
+// whenever the step is well posed.
+__device__ __forceinline__ double rcp_straight(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
+// value of v held by the lane below / above (column j-1 / j+1); 0 at the end of the wave
+__device__ __forceinline__ double lane_below(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);  // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_above(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);  // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int VAR, int REACT, bool LAST>
+__global__ void __launch_bounds__(64 * StripShape<VAR>::W) __attribute__((amdgpu_waves_per_eu(LAST ? StripShape<VAR>::OCC_LAST : StripShape<VAR>::OCC)))
+k_solve_strip(const BlockedArgs A) {
+    constexpr int R = StripShape<VAR>::R, W = StripShape<VAR>::W;
+    constexpr bool LEAN = (VAR == VAR_T);
+    __shared__ double seam[2][W][2][kSTile];  // [parity][wave][first/last row of the strip][lane]
+    __shared__ double2 rowc[LEAN ? kSTile : 1];  // lean rows: (dt J_e, dt J_w) of each tile row
+    const int lane = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const GridDev& g = A.g;
+    const ModelC& m = A.m;
+    const int H = A.H, HC = strip_col_halo(H);
+    const int TIR = kSTile - 2 * H, TIC = kSTile - 2 * HC;
+
+    // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2); give each XCD
+    // a contiguous run of tiles so that neighbouring tiles' halos hit the same L2.
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q = nb / 8, rem = nb % 8, xcd = bid % 8;
+    const int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
+    const int ty = t / A.tiles_x, tx = t % A.tiles_x;
+    const int row0 = A.r0 + ty * TIR - H + R * wave;  // local row of this thread's node k = 0
+    const int j = tx * TIC - HC + lane;
+    const int jc = min(max(j, 0), g.ncols - 1);
+    const bool col_interior = (j >= 1 && j <= g.M - 1);
+    const int rmax = g.nrows - 1;
+
+    // ---- loads: clamped coordinates, no branches.  rhs_in holds b = rhs/diag = delta^1; the first
+    // launch of a chain starts from it (d_in == rhs_in)
+    double d[R], b[R];
+    double cpv[R + 2];  // cp at rows row0-1 .. row0+R
+    double Tv[R + 2];   // lagged T at the same rows (cl, cd systems)
+    double clv[R], csv[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const size_t c = (size_t)min(max(row0 + k, 0), rmax) * g.ld + jc;
+        b[k] = A.rhs_in[c];
+        if (LEAN) d[k] = A.d_in[c];  // (the same line as b[k] in the first launch of a chain)
+        if (VAR == VAR_CD) {
+            clv[k] = A.a.clo[c];
+            csv[k] = A.a.cs1[c];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < R + 2; ++k) {
+        if (LEAN && (k == 0 || k == R + 1)) continue;
+        const size_t c = (size_t)min(max(row0 + k - 1, 0), rmax) * g.ld + jc;
+        cpv[k] = A.a.cp1[c];
+        if (!LEAN) Tv[k] = A.a.To[c];
+    }
+    const double rks = g.rk[jc], rkn = g.rk[min(jc + 1, g.ncols - 1)], rkm = g.rkm[jc];
+
+    // ---- matrix rows
+    // full rows (cl, cd): ce..cs scaled by 1/diag.  Every face coefficient is evaluated once: the
+    // x face between rows k-1 and k is carried from one node to the next, the y face comes from
+    // the lane below.
+    // lean rows (T): inv = 1/diag per node, the e/w off-diagonals per row (LDS), on/os per lane.
+    double ce[LEAN ? 1 : R], cw[LEAN ? 1 : R], cn[LEAN ? 1 : R], cs[LEAN ? 1 : R];
+    double inv[LEAN ? R : 1];
+    double on = 0.0, os = 0.0;
+    // cl: Dl at a face = Dl_max exp(-phi_l (c_a + c_b)/2) = Dl_max e_a e_b with e = exp(-phi_l c/2)
+    // per node -- one exponential per node instead of one per face
+    double ev[VAR == VAR_CL ? R + 2 : 1];
+    if (VAR == VAR_CL) {
+        // one wave-uniform choice between the short series and the library routine for the whole strip
+        // (tedd_exp's per-value branch would split the set-up into dozens of basic blocks)
+        bool small = true;
+#pragma unroll
+        for (int k = 0; k < R + 2; ++k) {
+            ev[k] = (-0.5 * m.phi_l) * cpv[k];
+            small = small && fabs(ev[k]) < 0x1p-10;
+        }
+        if (__all(small)) {
+#pragma unroll
+            for (int k = 0; k < R + 2; ++k) {
+                const double x = ev[k];
+                ev[k] = 1.0 + x * (1.0 + x * (0.5 + x * (1.0 / 6.0 + x * (1.0 / 24.0 + x * (1.0 / 120.0)))));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < R + 2; ++k) ev[k] = exp(ev[k]);
+        }
+    }
+    auto x_face = [&](int k) {  // face between rows row0+k-1 and row0+k
+        if (VAR == VAR_CL) return m.Dl_max * (ev[k + 1] * ev[k]);
+        return law_Dd(m, 0.5 * (cpv[k + 1] + cpv[k]), 0.5 * (Tv[k + 1] + Tv[k]));
+    };
+    auto is_active = [&](int li) {  // nodes the system has an unknown at
+        const int i = g.i0 + li;
+        return col_interior && li >= 1 && li <= g.nrows - 2 && i >= 1 && i <= g.N - 1;
+    };
+    double Dw = 0.0;
+    if (!LEAN) Dw = x_face(0);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int li = row0 + k;
+        const int lic = min(max(li, 0), rmax);
+        const Geo ge{g.rh[lic], g.rh[min(lic + 1, rmax)], g.rhm[lic], rks, rkn, rkm};
+        const bool active = is_active(li);
+        Coef5 r;
+        if (LEAN) {
+            r = jac_T_FT(m, ge, cpv[k + 1]);
+            const double iv = tedd_div(1.0, 2.0 - A.dt * r.c);
+            inv[k] = active ? iv : 0.0;
+            if (lane == 0) rowc[R * wave + k] = make_double2(A.dt * r.e, A.dt * r.w);  // read back by this wave only
+            on = A.dt * r.n;
+            os = A.dt * r.s;
+        } else {
+            double Dn;
+            if (VAR == VAR_CL)
+                Dn = m.Dl_max * (lane_above(ev[k + 1]) * ev[k + 1]);
+            else
+                Dn = law_Dd(m, 0.5 * (lane_above(cpv[k + 1]) + cpv[k + 1]), 0.5 * (lane_above(Tv[k + 1]) + Tv[k + 1]));
+            const double Dee = x_face(k + 1);
+            const Face4 D{Dw, Dee, lane_below(Dn), Dn};
+            Dw = Dee;
+            if (VAR == VAR_CL) {
+                St5 T;
+                T.c = 0.0; T.n = 0.0; T.s = 0.0;
+                T.e = Tv[k + 2];
+                T.w = Tv[k];
+                r = jac_cl_Fcl(m, ge, D, T, cpv[k + 1], 1.0, 1.0);
+            } else {
+                r = jac_cd_Fcd<REACT>(m, ge, D, clv[k], csv[k]);
+                const double tmp = r.w;  // reference quirk: W and S coefficients exchanged in the cd matrix
+                r.w = r.s;
+                r.s = tmp;
+            }
+            const double iv = rcp_straight(2.0 - A.dt * r.c);
+            ce[k] = active ? (A.dt * r.e) * iv : 0.0;
+            cw[k] = active ? (A.dt * r.w) * iv : 0.0;
+            cn[k] = active ? (A.dt * r.n) * iv : 0.0;
+            cs[k] = active ? (A.dt * r.s) * iv : 0.0;
+        }
+        b[k] = active ? b[k] : 0.0;
+        if (LEAN) d[k] = active ? d[k] : 0.0;
+    }
+    // full rows: the iterate is loaded last, until here the registers hold the inputs of the rows.
+    // (The empty asm ties the load addresses to the end of the set-up so that the loads are not hoisted.)
+    if (LEAN) {
+    } else if (A.d_in == A.rhs_in) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) d[k] = b[k];
+    } else {
+        int jd = jc;
+        asm volatile("" : "+v"(jd) : "v"(b[R - 1]));
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double v = A.d_in[(size_t)min(max(row0 + k, 0), rmax) * g.ld + jd];
+            d[k] = is_active(row0 + k) ? v : 0.0;
+        }
+    }
+
+    // which of this thread's nodes are written back, and which of those count for the record
+    const bool lane_in = (lane >= HC && lane < kSTile - HC && j >= 0 && j < g.ncols);
+    double up_max = 0.0, mag_max = 0.0;
+
+    // ---- sweeps
+    int par = 0;
+    for (int sw = 1; sw <= A.nsweeps; ++sw) {
+        seam[par][wave][0][lane] = d[0];
+        seam[par][wave][1][lane] = d[R - 1];
+        __syncthreads();
+        const double above = seam[par][max(wave - 1, 0)][1][lane];      // row row0-1 (unused for wave 0)
+        const double below = seam[par][min(wave + 1, W - 1)][0][lane];  // row row0+R (unused for the last wave)
+        par ^= 1;
+        const bool track = LAST && sw == A.nsweeps;
+        double prev = above;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int r = R * wave + k;
+            const double cur = d[k];
+            const double nxt = (k < R - 1) ? d[k + 1] : below;
+            double v;
+            if (LEAN) {
+                const double2 rc = rowc[R * wave + k];
+                v = b[k] + inv[k] * (rc.x * nxt + rc.y * prev + on * lane_above(cur) + os * lane_below(cur));
+            } else
+                v = b[k] + ce[k] * nxt + cw[k] * prev + cn[k] * lane_above(cur) + cs[k] * lane_below(cur);
+            d[k] = v;
+            if (track) {
+                const int li = row0 + k;
+                const bool counted = lane_in && r >= H && r < kSTile - H && li >= A.r0 && li < A.r1 && is_interior(g, li, j);
+                const double up = counted ? fabs(v - cur) : 0.0;
+                up_max = (up > up_max || up != up) ? up : up_max;
+            }
+            prev = cur;
+        }
+    }
+
+    // ---- write back the tile interior.  The coordinates are laundered through empty asm so that
+    // the store addresses are rebuilt here instead of being kept in registers across the sweeps.
+    const double* uo = (VAR == VAR_T) ? A.a.To : (VAR == VAR_CL) ? A.a.clo : A.a.cdo;
+    int row0w = row0, jw = j;
+    asm volatile("" : "+s"(row0w));
+    asm volatile("" : "+v"(jw));
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int r = R * wave + k;
+        const int li = row0w + k;
+        if (r >= H && r < kSTile - H && li >= A.r0 && li < A.r1 && lane_in) {
+            const size_t c = at(g, li, jw);
+            const double dn = d[k];
+            if (LAST) {
+                if (is_interior(g, li, jw)) {
+                    A.u_out[c] = uo[c] + dn;
+                    const double mag = fabs(dn);
+                    mag_max = (mag > mag_max || mag != mag) ? mag : mag_max;
+                } else {
+                    A.u_out[c] = (VAR == VAR_T) ? 0.0 : uo[c];
+                }
+            } else {
+                A.d_out[c] = dn;
+            }
+        }
+    }
+    if (LAST) {
+        if (A.nsweeps == 0) up_max = mag_max;
+        __syncthreads();  // the seam rows are dead: reuse their first doubles
+        double* red = &seam[0][0][0][0];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o1 = __shfl_xor(up_max, off, 64), o2 = __shfl_xor(mag_max, off, 64);
+            up_max = (o1 > up_max || o1 != o1) ? o1 : up_max;
+            mag_max = (o2 > mag_max || o2 != o2) ? o2 : mag_max;
+        }
+        if (lane == 0) {
+            red[2 * wave] = up_max;
+            red[2 * wave + 1] = mag_max;
+        }
+        __syncthreads();
+        if (wave == 0 && lane < 2) {
+            double v = red[lane];
+            for (int w2 = 1; w2 < W; ++w2) {
+                const double o = red[2 * w2 + lane];
+                v = (o > v || o != o) ? o : v;
+            }
+            if (v != v) v = INFINITY;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+            // most tiles do not raise the maximum: skip their atomics
+            if (bits > __atomic_load_n(A.stats + lane, __ATOMIC_RELAXED)) atomicMax(A.stats + lane, bits);
+        }
+    }
+}
+
+}  // namespace tedd

@@ -50,3 +50,12 @@ def test_integrator_steps(tag):
     err, res_err, stats = cc.run_steps(tag)
     assert err < (2e-12 if "bigdt" in tag else 5e-14), (tag, err, stats)
     assert res_err < 1e-13, (tag, res_err)
+
+
+@pytest.mark.parametrize("tag", cc.tags("golden_steps.npz", "/t0"))
+def test_integrator_steps_with_forcing_evaluated_inside_the_step_kernels(tag):
+    if not tag.startswith("pc"):
+        pytest.skip("the forcing cache serves the predictor-corrector step")
+    err, res_err, stats = cc.run_steps(tag, options={"cache_forcing": 0})
+    assert err < (2e-12 if "bigdt" in tag else 5e-14), (tag, err, stats)
+    assert res_err < 1e-13, (tag, res_err)
