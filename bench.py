@@ -49,6 +49,8 @@ def arrays_per_launch(solver, cache_forcing, sweeps, hmax):
         a["predict"] = 12       # reads cp,T,cl,cd,cs + cached fcp(t0); writes Y_T,Y_cl,Y_cd,cp*,cs*,fcp(t1)
         a["cs_newton"] = 12     # reads cp,T,cl,cd,cs, T_new,cl_new,cd_new, fcp(t0), fcp(t1); writes cp_new, cs_new
         f = 0
+    if solver == "strip":
+        a["predict"] += 1 + f   # + reads fT(t1), writes b = rhs/diag of the T system (no rhs_T launch)
     w = 1 if solver == "strip" else 2           # strip: writes b = rhs/diag; others: rhs and delta_1
     a["rhs_T"] = 3 + f + w      # reads cp*, T, Y_T
     a["rhs_cl"] = 5 + f + w     # reads cp*, T, T_new, cl, Y_cl

@@ -685,6 +685,7 @@ public:
     // options
     int opt_blocked = 2;      // 0: one launch per sweep; 1: LDS-blocked chain; 2: register-resident chain (backends that have them)
     int opt_hmax = 0;         // sweeps fused per launch (0 = automatic)
+    bool bT_ready = false;    // slot DA holds rhs/diag of the next T system (written by the predictor launch)
     int opt_fuse_rhs[3] = {1, 1, 1};  // per system (T, cl, cd): compute the rhs inside the first blocked launch
 
     template <int VAR, int CASE, int REACT>
@@ -810,9 +811,13 @@ public:
             else
                 r = need({{a.cp1, true}, {a.To, true}, {a.cdo, true}, {a.clo, false}, {a.cs1, false}, {a.Tn, true},
                           {a.cln, false}, {a.Ycd, false}});
-            NewtonRhsFn<VAR, CASE, REACT> fr{A.g, model, A.tb, f1, a, nullptr, bsc, p.dt};
-            be.nodes(fam_rhs, fr, r.lo, r.hi, ncols);
-            mark(bsc, r);
+            if (VAR == VAR_T && bT_ready) {
+                bT_ready = false;  // b came with the predictor launch
+            } else {
+                NewtonRhsFn<VAR, CASE, REACT> fr{A.g, model, A.tb, f1, a, nullptr, bsc, p.dt};
+                be.nodes(fam_rhs, fr, r.lo, r.hi, ncols);
+                mark(bsc, r);
+            }
             const double* din = bsc;
             for (int l = 0; l < L; ++l) {
                 const int ns = (remaining + (L - l) - 1) / (L - l);
@@ -939,10 +944,16 @@ public:
         {
             Range r = need({{cur[0], true}, {cur[1], true}, {cur[2], true}, {cur[3], true}, {cur[4], false},
                             {fcp_t0, false}});
+            // the register-resident solve iterates on b = rhs/diag; for the first T system the predictor
+            // kernel has everything b needs
+            double* bT = nullptr;
+            if (Backend::kHasBlockedSolve && opt_blocked == 2 && p.num_pc > 0 && p.num_newton > 0) bT = B(DA);
             PredictFn<CASE, REACT> f{g, model, tb, f0, f1, fields(cur), YT, Ycl, Ycd, cpP, csP, fcp_t0, fcp_t0_out,
-                                     fcp_t1_out, dt};
+                                     fcp_t1_out, dt, bT};
             be.nodes(FAM_PREDICT, f, r.lo, r.hi, ncols);
             for (double* q : {YT, Ycl, Ycd, cpP, csP}) mark(q, r);
+            if (bT) mark(bT, r);
+            bT_ready = (bT != nullptr);
             if (fcp_t0_out) {
                 mark(fcp_t0_out, r);
                 fcp_t0 = fcp_t0_out;

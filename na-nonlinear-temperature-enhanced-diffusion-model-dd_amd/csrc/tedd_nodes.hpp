@@ -150,6 +150,9 @@ struct PredictFn {
     double* fcp_t0_out;
     double* fcp_t1_out;
     double dt;
+    // optional: rhs/diag of the first Newton system for T (its lagged state is S with the predicted
+    // cp, all of it known at this node), so that no separate right-hand-side launch is needed
+    double* bT;
     TEDD_HD void operator()(int li, int j) const {
         const bool in = is_interior(g, li, j);
         const size_t c = at(g, li, j);
@@ -158,17 +161,20 @@ struct PredictFn {
         const F5 F = node_field<REACT>(m, g, S, fa, li, j, in);
         const double cp0 = S.v[VAR_CP][c], T0 = S.v[VAR_T][c], cl0 = S.v[VAR_CL][c], cd0 = S.v[VAR_CD][c],
                      cs0 = S.v[VAR_CS][c];
-        YT[c] = dt * F.T + 2.0 * T0;
+        const double YTv = dt * F.T + 2.0 * T0;
+        YT[c] = YTv;
         Ycl[c] = dt * F.cl + 2.0 * cl0;
         Ycd[c] = dt * F.cd + 2.0 * cd0;
         // forcing at t1: only fcp (cell average) and fcs are needed here
-        double fcp1, fcs1;
+        double fcp1, fcs1, fT1 = 0.0;
         if (CASE == CASE_STREAM) {
             fcp1 = f1.f[0][c];
             fcs1 = f1.f[4][c];
+            if (bT) fT1 = f1.f[1][c];
         } else {
             const MmsPt p1 = mms_node<CASE>(m, f1.tm, tb, li, j);
             fcs1 = mms_fcs<REACT>(m, p1);
+            fT1 = mms_fT(m, p1);
             fcp1 = in ? mms_fcp_cellavg<CASE>(m, f1.tm, tb, li, j) : 0.0;
             if (fcp_t0_out) fcp_t0_out[c] = fa.fcp;
             if (fcp_t1_out) fcp_t1_out[c] = fcp1;
@@ -176,7 +182,18 @@ struct PredictFn {
         // Heun for cp (other fields frozen at t0)
         const double cps = cp0 + dt * F.cp;
         const double Fcps = fcp1 + (in ? rhs_cp(m, cps, T0, cl0) : 0.0);
-        cp1[c] = cp0 + 0.5 * dt * (F.cp + Fcps);
+        const double cp1v = cp0 + 0.5 * dt * (F.cp + Fcps);
+        cp1[c] = cp1v;
+        if (bT) {  // same arithmetic as newton_rhs_value<VAR_T> / newton_row<VAR_T>
+            double bv = 0.0;
+            if (in) {
+                const Geo ge = geo_at(g, li, j);
+                const St5 T = load5(S.v[VAR_T], g, li, j);
+                const double r = YTv - (2.0 * T.c - dt * (fT1 + rhs_T(m, ge, T, cp1v)));
+                bv = tedd_div(r, 2.0 - dt * jac_T_FT(m, ge, cp1v).c);
+            }
+            bT[c] = bv;
+        }
         // Heun for cs
         const double css = cs0 + dt * F.cs;
         const double Fcss = in ? (fcs1 - reaction<REACT>(m, cl0, cd0, css)) : 0.0;

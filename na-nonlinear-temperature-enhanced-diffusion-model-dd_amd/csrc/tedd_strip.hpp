@@ -42,7 +42,7 @@ struct StripShape {
     static constexpr int R = 16;                        // rows per thread
     static constexpr int W = kSTile / R;                // waves per workgroup
     static constexpr int OCC = (VAR == VAR_T) ? 4 : 2;  // waves per SIMD the register budget is set for
-    static constexpr int OCC_LAST = (VAR == VAR_T) ? 3 : 2;  // the launch that also keeps the record
+    static constexpr int OCC_LAST = (VAR == VAR_T) ? 4 : 2;  // the launch that also keeps the record
 };
 
 // column halo of a launch of depth H: a multiple of 8 nodes, so that the 64-node row segments a
@@ -225,35 +225,42 @@ k_solve_strip(const BlockedArgs A) {
         }
     }
 
-    // which of this thread's nodes are written back, and which of those count for the record
+    // which of this thread's nodes are written back
     const bool lane_in = (lane >= HC && lane < kSTile - HC && j >= 0 && j < g.ncols);
     double up_max = 0.0, mag_max = 0.0;
 
-    // ---- sweeps
+    // ---- sweeps.  The last launch of a chain keeps its final sweep for the write-back below.
     int par = 0;
-    for (int sw = 1; sw <= A.nsweeps; ++sw) {
+    double above = 0.0, below = 0.0;
+    auto exchange_seams = [&]() {
         seam[par][wave][0][lane] = d[0];
         seam[par][wave][1][lane] = d[R - 1];
         __syncthreads();
-        const double above = seam[par][max(wave - 1, 0)][1][lane];      // row row0-1 (unused for wave 0)
-        const double below = seam[par][min(wave + 1, W - 1)][0][lane];  // row row0+R (unused for the last wave)
+        above = seam[par][max(wave - 1, 0)][1][lane];      // row row0-1 (unused for wave 0)
+        below = seam[par][min(wave + 1, W - 1)][0][lane];  // row row0+R (unused for the last wave)
         par ^= 1;
-        const bool track = LAST && sw == A.nsweeps;
+    };
+    auto update = [&](int k, double prev, double cur, double nxt) {
+        if (LEAN) {
+            const double2 rc = rowc[R * wave + k];
+            return b[k] + inv[k] * (rc.x * nxt + rc.y * prev + on * lane_above(cur) + os * lane_below(cur));
+        }
+        return b[k] + ce[k] * nxt + cw[k] * prev + cn[k] * lane_above(cur) + cs[k] * lane_below(cur);
+    };
+    // (lean rows have the registers to fuse the final sweep with the store; full rows do it in place)
+    constexpr bool FUSE_FINAL = LAST && LEAN;
+    const int in_place = FUSE_FINAL ? max(A.nsweeps - 1, 0) : A.nsweeps;
+    for (int sw = 1; sw <= in_place; ++sw) {
+        exchange_seams();
+        const bool track = LAST && !FUSE_FINAL && sw == A.nsweeps;
         double prev = above;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const int r = R * wave + k;
             const double cur = d[k];
-            const double nxt = (k < R - 1) ? d[k + 1] : below;
-            double v;
-            if (LEAN) {
-                const double2 rc = rowc[R * wave + k];
-                v = b[k] + inv[k] * (rc.x * nxt + rc.y * prev + on * lane_above(cur) + os * lane_below(cur));
-            } else
-                v = b[k] + ce[k] * nxt + cw[k] * prev + cn[k] * lane_above(cur) + cs[k] * lane_below(cur);
+            const double v = update(k, prev, cur, (k < R - 1) ? d[k + 1] : below);
             d[k] = v;
             if (track) {
-                const int li = row0 + k;
+                const int r = R * wave + k, li = row0 + k;
                 const bool counted = lane_in && r >= H && r < kSTile - H && li >= A.r0 && li < A.r1 && is_interior(g, li, j);
                 const double up = counted ? fabs(v - cur) : 0.0;
                 up_max = (up > up_max || up != up) ? up : up_max;
@@ -268,28 +275,56 @@ k_solve_strip(const BlockedArgs A) {
     int row0w = row0, jw = j;
     asm volatile("" : "+s"(row0w));
     asm volatile("" : "+v"(jw));
+    if (FUSE_FINAL) {
+        // final sweep fused with the store: new unknown = lagged unknown + delta, boundary rule, and
+        // the record max|delta^S - delta^(S-1)|, max|delta^S| over the interior nodes written here
+        const bool sweep = A.nsweeps > 0;
+        if (sweep) exchange_seams();
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const int r = R * wave + k;
-        const int li = row0w + k;
-        if (r >= H && r < kSTile - H && li >= A.r0 && li < A.r1 && lane_in) {
-            const size_t c = at(g, li, jw);
-            const double dn = d[k];
-            if (LAST) {
+        for (int k = 0; k < R; ++k) {
+            const int r = R * wave + k;
+            const int li = row0w + k;
+            const double cur = d[k];
+            const double prev = (k > 0) ? d[k - 1] : above, nxt = (k < R - 1) ? d[k + 1] : below;
+            const double dn = sweep ? update(k, prev, cur, nxt) : cur;  // (all lanes take part in the lane shifts)
+            if (r >= H && r < kSTile - H && li >= A.r0 && li < A.r1 && lane_in) {
+                const size_t c = at(g, li, jw);
                 if (is_interior(g, li, jw)) {
                     A.u_out[c] = uo[c] + dn;
-                    const double mag = fabs(dn);
+                    const double up = sweep ? fabs(dn - cur) : fabs(dn), mag = fabs(dn);
+                    up_max = (up > up_max || up != up) ? up : up_max;
                     mag_max = (mag > mag_max || mag != mag) ? mag : mag_max;
                 } else {
                     A.u_out[c] = (VAR == VAR_T) ? 0.0 : uo[c];
                 }
-            } else {
-                A.d_out[c] = dn;
             }
+        }
+    } else if (LAST) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int r = R * wave + k;
+            const int li = row0w + k;
+            if (r >= H && r < kSTile - H && li >= A.r0 && li < A.r1 && lane_in) {
+                const size_t c = at(g, li, jw);
+                if (is_interior(g, li, jw)) {
+                    A.u_out[c] = uo[c] + d[k];
+                    const double mag = fabs(d[k]);
+                    mag_max = (mag > mag_max || mag != mag) ? mag : mag_max;
+                } else {
+                    A.u_out[c] = (VAR == VAR_T) ? 0.0 : uo[c];
+                }
+            }
+        }
+        if (A.nsweeps == 0) up_max = mag_max;
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int r = R * wave + k;
+            const int li = row0w + k;
+            if (r >= H && r < kSTile - H && li >= A.r0 && li < A.r1 && lane_in) A.d_out[at(g, li, jw)] = d[k];
         }
     }
     if (LAST) {
-        if (A.nsweeps == 0) up_max = mag_max;
         __syncthreads();  // the seam rows are dead: reuse their first doubles
         double* red = &seam[0][0][0][0];
 #pragma unroll
