@@ -42,13 +42,12 @@ def arrays_per_launch(solver, cache_forcing, sweeps, hmax):
     a = {}
     if cache_forcing:
         a["forcing"] = 5        # writes fcp (cell averages), fT, fcl, fcd, fcs of the new time level
-        a["predict"] = 17       # reads cp,T,cl,cd,cs, the 5 forcing arrays at t0, fcp and fcs at t1; writes Y_T,Y_cl,Y_cd,cp*,cs*
-        a["cs_newton"] = 14     # reads cp,T,cl,cd,cs, T_new,cl_new,cd_new, fcp and fcs at t0 and t1; writes cp_new, cs_new
+        a["predict"] = 19       # reads cp,T,cl,cd,cs, the 5 forcing arrays at t0, fcp and fcs at t1; writes Y_T,Y_cl,Y_cd,cp*,cs*, and the t0 parts of the correctors (2)
         f = 1                   # the forcing array each rhs kernel reads
     else:
-        a["predict"] = 12       # reads cp,T,cl,cd,cs + cached fcp(t0); writes Y_T,Y_cl,Y_cd,cp*,cs*,fcp(t1)
-        a["cs_newton"] = 12     # reads cp,T,cl,cd,cs, T_new,cl_new,cd_new, fcp(t0), fcp(t1); writes cp_new, cs_new
+        a["predict"] = 14       # reads cp,T,cl,cd,cs + cached fcp(t0); writes Y_T,Y_cl,Y_cd,cp*,cs*,fcp(t1), corrector parts (2)
         f = 0
+    a["cs_newton"] = 8          # reads the 2 corrector parts, cs, T_new, cl_new, cd_new; writes cp_new, cs_new
     if solver == "strip":
         a["predict"] += 1 + f   # + reads fT(t1), writes b = rhs/diag of the T system (no rhs_T launch)
     w = 1 if solver == "strip" else 2           # strip: writes b = rhs/diag; others: rhs and delta_1

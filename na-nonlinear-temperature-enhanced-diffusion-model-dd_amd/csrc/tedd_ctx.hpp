@@ -909,7 +909,6 @@ public:
 
         // cp-forcing cell averages: reuse the array the last step computed for this time level
         const double* fcp_t0 = nullptr;
-        const double* fcp_t1 = nullptr;
         double* fcp_t0_out = nullptr;
         double* fcp_t1_out = nullptr;
         if (CASE != CASE_STREAM) {
@@ -941,6 +940,8 @@ public:
         };
         double* cpP = grab();
         double* csP = grab();
+        double* ncp = grab();  // t0 parts of the correctors
+        double* ycs = grab();
         {
             Range r = need({{cur[0], true}, {cur[1], true}, {cur[2], true}, {cur[3], true}, {cur[4], false},
                             {fcp_t0, false}});
@@ -949,19 +950,16 @@ public:
             double* bT = nullptr;
             if (Backend::kHasBlockedSolve && opt_blocked == 2 && p.num_pc > 0 && p.num_newton > 0) bT = B(DA);
             PredictFn<CASE, REACT> f{g, model, tb, f0, f1, fields(cur), YT, Ycl, Ycd, cpP, csP, fcp_t0, fcp_t0_out,
-                                     fcp_t1_out, dt, bT};
+                                     fcp_t1_out, dt, bT, ncp, ycs};
             be.nodes(FAM_PREDICT, f, r.lo, r.hi, ncols);
-            for (double* q : {YT, Ycl, Ycd, cpP, csP}) mark(q, r);
+            for (double* q : {YT, Ycl, Ycd, cpP, csP, ncp, ycs}) mark(q, r);
             if (bT) mark(bT, r);
             bT_ready = (bT != nullptr);
             if (fcp_t0_out) {
                 mark(fcp_t0_out, r);
                 fcp_t0 = fcp_t0_out;
             }
-            if (fcp_t1_out) {
-                mark(fcp_t1_out, r);
-                fcp_t1 = fcp_t1_out;
-            }
+            if (fcp_t1_out) mark(fcp_t1_out, r);
         }
 
         // iterate: Newton on T -> cl -> cd with cp, cs frozen, then correct cp, cs
@@ -999,9 +997,8 @@ public:
             }
             double* cpN = grab();
             double* csN = grab();
-            CorrectIn<CASE, REACT> ci{g, model, tb, f0, f1, fields(cur), To, clo, cdo, fcp_t0, fcp_t1, dt};
-            Range r = need({{cur[0], false}, {cur[1], false}, {cur[2], false}, {cur[3], false}, {cur[4], false},
-                            {To, false}, {clo, false}, {cdo, false}, {fcp_t0, false}, {fcp_t1, false}});
+            CorrectIn<CASE, REACT> ci{g, model, ncp, ycs, cur[VAR_CS], To, clo, cdo, dt};
+            Range r = need({{ncp, false}, {ycs, false}, {cur[VAR_CS], false}, {To, false}, {clo, false}, {cdo, false}});
             be.template correct<CASE, REACT>(ci, r.lo, r.hi, ncols, cpN, csN, p.cs_iters, p.cs_rtol, d_ints);
             mark(cpN, r);
             mark(csN, r);

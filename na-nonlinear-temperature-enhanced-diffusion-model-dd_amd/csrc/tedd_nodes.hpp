@@ -137,7 +137,7 @@ struct FieldFn {
 // ------------------------------------------------------------------------------------
 // K_pred: Y_v = dt F_v(S0,t0) + 2 v0 for v in {T,cl,cd}; Heun predictors for cp and cs.
 // fcp_t0 (optional): cell-averaged cp-forcing at t0 computed by the previous step;
-// fcp_t1 (optional): where to keep the one at t1 for the corrector and the next step.
+// fcp_t1 (optional): where to keep the one at t1 for the next step.
 template <int CASE, int REACT>
 struct PredictFn {
     GridDev g;
@@ -153,6 +153,11 @@ struct PredictFn {
     // optional: rhs/diag of the first Newton system for T (its lagged state is S with the predicted
     // cp, all of it known at this node), so that no separate right-hand-side launch is needed
     double* bT;
+    // the parts of the correctors that depend on the t0 state and the forcing only:
+    // ncp = (1 + dt/2 al0) cp0 + dt/2 (fcp0 + fcp1)           (prob1base.py:2967-2996)
+    // ycs = 2 cs0 - dt R(S0) + dt (fcs0 + fcs1)   (RegHCsTriple, prob1base.py:3665-3702)
+    //     = (1 + dt/2 b0) cs0 + dt/2 (fcs0 + fcs1)    (CsTriple, prob1base.py:3190-3219)
+    double *ncp, *ycs;
     TEDD_HD void operator()(int li, int j) const {
         const bool in = is_interior(g, li, j);
         const size_t c = at(g, li, j);
@@ -199,6 +204,16 @@ struct PredictFn {
         const double Fcss = in ? (fcs1 - reaction<REACT>(m, cl0, cd0, css)) : 0.0;
         const double v = cs0 + (0.5 * dt) * (F.cs + Fcss);
         cs1[c] = (REACT == REACT_REG) ? (in ? v : 0.0 * v) : v;
+        // corrector inputs
+        const double h = dt / 2;
+        const double al0 = -m.K2 * T0 - m.K1 * (cl0 + 1.0);
+        ncp[c] = in ? (1.0 + h * al0) * cp0 + h * (fa.fcp + fcp1) : 0.0;
+        if (REACT == REACT_REG) {
+            ycs[c] = 2.0 * cs0 - dt * m.Kd * (m.Sd - cd0) * (cl0 + 1.0) * heaviside_reg(cs0, m.eta) + dt * (fa.fcs + fcs1);
+        } else {
+            const double b0 = -m.Kd * (m.Sd - cd0) * (1.0 + cl0);
+            ycs[c] = in ? (1.0 + h * b0) * cs0 + h * (fa.fcs + fcs1) : 0.0;
+        }
     }
 };
 
@@ -427,15 +442,15 @@ struct ResidualFn {
 // closed-form trapezoid (3190-3219).  cs for RegHCsTriple: scalar Newton per node
 // (3647-3702); the per-node inputs y, a are prepared by cs_newton_inputs and iterated by
 // cs_newton_step; the kernel/loop around them reproduces the reference's global early exit.
+// Everything that depends on the t0 state and the forcing only was folded into ncp, ycs by the
+// predictor launch, so a corrector launch reads 6 arrays instead of 12.
 template <int CASE, int REACT>
 struct CorrectIn {
     GridDev g;
     ModelC m;
-    MmsTabs tb;
-    ForcingSrc f0, f1;
-    Fields5 S0;
+    const double *ncp, *ycs;  // from PredictFn
+    const double* cs0;        // cs at t0: starting value of the scalar Newton iteration
     const double *T1, *cl1, *cd1;
-    const double *fcp_t0, *fcp_t1;  // cached cell averages (closed-form cases); may be null
     double dt;
 };
 
@@ -443,59 +458,30 @@ template <int CASE, int REACT>
 TEDD_HD double corrector_cp(const CorrectIn<CASE, REACT>& a, int li, int j) {
     const size_t c = at(a.g, li, j);
     if (!is_interior(a.g, li, j)) return 0.0;
-    double s0, s1;
-    if (CASE == CASE_STREAM) {
-        s0 = a.f0.f[0][c];
-        s1 = a.f1.f[0][c];
-    } else {
-        s0 = a.fcp_t0 ? a.fcp_t0[c] : mms_fcp_cellavg<CASE>(a.m, a.f0.tm, a.tb, li, j);
-        s1 = a.fcp_t1 ? a.fcp_t1[c] : mms_fcp_cellavg<CASE>(a.m, a.f1.tm, a.tb, li, j);
-    }
     const ModelC& m = a.m;
     const double h = a.dt / 2;
-    const double al0 = -m.K2 * a.S0.v[VAR_T][c] - m.K1 * (a.S0.v[VAR_CL][c] + 1.0);
     const double al1 = -m.K2 * a.T1[c] - m.K1 * (a.cl1[c] + 1.0);
-    const double num = (1.0 + h * al0) * a.S0.v[VAR_CP][c] + h * (s0 + s1);
-    return tedd_div(num, 1.0 - h * al1);
-}
-
-template <int CASE, int REACT>
-TEDD_HD void forcing_fcs_pair(const CorrectIn<CASE, REACT>& a, int li, int j, double& s0, double& s1) {
-    const size_t c = at(a.g, li, j);
-    if (CASE == CASE_STREAM) {
-        s0 = a.f0.f[4][c];
-        s1 = a.f1.f[4][c];
-    } else {
-        s0 = mms_fcs<REACT>(a.m, mms_node<CASE>(a.m, a.f0.tm, a.tb, li, j));
-        s1 = mms_fcs<REACT>(a.m, mms_node<CASE>(a.m, a.f1.tm, a.tb, li, j));
-    }
+    return tedd_div(a.ncp[c], 1.0 - h * al1);
 }
 
 template <int CASE, int REACT>
 TEDD_HD double corrector_cs_closed_form(const CorrectIn<CASE, REACT>& a, int li, int j) {
     const size_t c = at(a.g, li, j);
     if (!is_interior(a.g, li, j)) return 0.0;
-    double s0, s1;
-    forcing_fcs_pair(a, li, j, s0, s1);
     const ModelC& m = a.m;
     const double h = a.dt / 2;
-    const double b0 = -m.Kd * (m.Sd - a.S0.v[VAR_CD][c]) * (1.0 + a.S0.v[VAR_CL][c]);
     const double b1 = -m.Kd * (m.Sd - a.cd1[c]) * (1.0 + a.cl1[c]);
-    const double num = (1.0 + h * b0) * a.S0.v[VAR_CS][c] + h * (s0 + s1);
-    return tedd_div(num, 1.0 - h * b1);
+    return tedd_div(a.ycs[c], 1.0 - h * b1);
 }
 
 // y and a of  2x + (2x - y) e^{-eta x} = y - a   (all nodes, boundary included)
 template <int CASE, int REACT>
 TEDD_HD void cs_newton_inputs(const CorrectIn<CASE, REACT>& a, int li, int j, double& y, double& av, double& x0) {
     const size_t c = at(a.g, li, j);
-    double s0, s1;
-    forcing_fcs_pair(a, li, j, s0, s1);
     const ModelC& m = a.m;
-    const double cs0 = a.S0.v[VAR_CS][c], cl0 = a.S0.v[VAR_CL][c], cd0 = a.S0.v[VAR_CD][c];
-    y = 2.0 * cs0 - a.dt * m.Kd * (m.Sd - cd0) * (cl0 + 1.0) * heaviside_reg(cs0, m.eta) + a.dt * (s0 + s1);
+    y = a.ycs[c];
     av = a.dt * m.Kd * (m.Sd - a.cd1[c]) * (a.cl1[c] + 1.0);
-    x0 = cs0;
+    x0 = a.cs0[c];
 }
 // one Newton update; returns dx
 TEDD_HD double cs_newton_step(double x, double y, double av, double eta) {
