@@ -78,6 +78,35 @@ def arrays_per_launch(solver, cache_forcing, sweeps, hmax):
     return a, chains
 
 
+# kernel-name fragment of each launch family in the rocprofv3 counter files
+FAMILY_KERNELS = {"predict": ["PredictFn"], "forcing": ["ForcingFn"], "cs_newton": ["k_cs_newton"],
+                  "rhs_T": ["NewtonRhsFn<1,"], "rhs_cl": ["NewtonRhsFn<2,"], "rhs_cd": ["NewtonRhsFn<3,"],
+                  "solve_T": ["k_solve_strip<1,", "k_solve_blocked<1,"], "solve_cl": ["k_solve_strip<2,", "k_solve_blocked<2,"],
+                  "solve_cd": ["k_solve_strip<3,", "k_solve_blocked<3,"]}
+
+
+def pmc_traffic(fam, config):
+    """HBM bytes per launch of a family from the committed PMC summary of this same configuration
+    (profiles/*_pmc_<N>.json, written by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE
+    passes): (2 x FETCH_SIZE + WRITE_SIZE) KB -- on gfx950 FETCH_SIZE tallies the 128-byte requests
+    of coalesced streaming reads at 64 bytes.  None if no summary matches the configuration."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{config['mesh_N']}.json")), reverse=True):
+        with open(path) as fh:
+            summ = json.load(fh)
+        if any(summ.get("config", {}).get(k) != config[k] for k in ("mesh_N", "solver", "sweeps_per_launch", "forcing")):
+            continue
+        tot, launches = 0.0, 0
+        for name, c in summ["kernels"].items():
+            if any(frag in name for frag in FAMILY_KERNELS.get(fam, [])) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                n = c["FETCH_SIZE"]["n"]
+                tot += (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024.0 * n
+                launches += n
+        if launches:
+            return {"bytes_per_launch": tot / launches, "source": os.path.relpath(path, ROOT)}
+    return None
+
+
 def consts_vec(d):
     from tedd import _ffi
     return [float(d[k]) for k in _ffi.CONST_NAMES]
@@ -144,7 +173,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the N=256 study-mesh and CPU-baseline legs")
     ap.add_argument("--solver", choices=["strip", "blocked", "sweeps"], default="strip",
                     help="Newton solve: register-resident chain | LDS-blocked chain | one launch per Jacobi sweep")
-    ap.add_argument("--hmax", type=int, default=8, help="Jacobi sweeps fused per launch of a solve chain")
+    ap.add_argument("--hmax", type=int, default=10, help="Jacobi sweeps fused per launch of a solve chain")
     ap.add_argument("--cache-forcing", type=int, default=1,
                     help="1: forcing arrays evaluated once per time level; 0: inside the step kernels")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (repeatable)")
@@ -240,6 +269,14 @@ def main():
     arrays_step = sum(arrays.get(k, 0) * v["launches"] for k, v in prof.items()) / args.steps
     step_gbs = 8.0 * (N + 1) * (N + 1) * arrays_step * args.steps / elapsed / 1e9
 
+    cfg_key = {"mesh_N": N, "solver": args.solver, "sweeps_per_launch": args.hmax,
+               "forcing": "arrays per time level" if args.cache_forcing else "closed form inside the step kernels"}
+    if roofline is not None:
+        tr = pmc_traffic(fam, cfg_key)
+        if tr is not None:
+            roofline["traffic"] = tr["bytes_per_launch"]
+            roofline["traffic_source"] = tr["source"]
+            roofline["algorithmic_bytes_per_launch"] = 8.0 * n_nodes_local * arrays.get(fam, 0)
     out = {
         "metric": "time-steps/sec, MMSCaseExpSin predictor-corrector (reghcstriple), synthetic 4096x mesh",
         "value": args.steps / elapsed, "unit": "time-steps/s", "n_gpus": world, "steps": args.steps,

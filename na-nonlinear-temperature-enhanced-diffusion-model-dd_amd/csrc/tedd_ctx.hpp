@@ -788,7 +788,9 @@ public:
             const int fam = (VAR == VAR_T) ? FAM_SOLVE_T : (VAR == VAR_CL) ? FAM_SOLVE_CL : FAM_SOLVE_CD;
             const int fam_rhs = (VAR == VAR_T) ? FAM_RHS_T : (VAR == VAR_CL) ? FAM_RHS_CL : FAM_RHS_CD;
             int remaining = nsweeps - 1;
-            int hmax = opt_hmax > 0 ? opt_hmax : 8;
+            // up to 10 sweeps per launch: measured best at 16384^2 (two launches of 10 + 9 for the T
+            // system beat three of 7 + 6 + 6 although the column halo is then no longer line-aligned)
+            int hmax = opt_hmax > 0 ? opt_hmax : 10;
             hmax = std::min(hmax, 16);
             const int L = std::max(1, (remaining + hmax - 1) / hmax);
             BlockedArgs A;
