@@ -80,6 +80,17 @@ TEDD_HD double law_dDd_dT(const ModelC& m, double c, double T) {
     return m.Dd_max * tedd_exp(-m.phi_d * c - x) * tedd_div(x, Te);
 }
 
+// Dd and dDd/dT at once: one reciprocal and one exponential instead of three divisions and two
+// exponentials (the right-hand side of the cd system needs both on every face)
+TEDD_HD void law_Dd_pair(const ModelC& m, double c, double T, double& D, double& dT) {
+    const double Te = T + m.T_shift;
+    const double rTe = tedd_div(1.0, (Te != 0.0) ? Te : 1.0);
+    const double x = m.phi_T * rTe;
+    const double E = m.Dd_max * tedd_exp(-m.phi_d * c - x);
+    D = (Te != 0.0) ? E : 0.0;
+    dT = (Te != 0.0) ? E * x * rTe : 0.0;
+}
+
 TEDD_HD double heaviside_reg(double x, double eta) { return tedd_div(1.0, 1.0 + exp(-eta * x)); }
 
 template <int REACT>
@@ -120,6 +131,12 @@ TEDD_HD Face4 faces_Dd(const ModelC& m, const St5& cp, const St5& T) {
                  law_Dd(m, 0.5 * (cp.e + cp.c), 0.5 * (T.e + T.c)),
                  law_Dd(m, 0.5 * (cp.c + cp.s), 0.5 * (T.c + T.s)),
                  law_Dd(m, 0.5 * (cp.n + cp.c), 0.5 * (T.n + T.c))};
+}
+TEDD_HD void faces_Dd_pair(const ModelC& m, const St5& cp, const St5& T, Face4& D, Face4& dT) {
+    law_Dd_pair(m, 0.5 * (cp.c + cp.w), 0.5 * (T.c + T.w), D.w, dT.w);
+    law_Dd_pair(m, 0.5 * (cp.e + cp.c), 0.5 * (T.e + T.c), D.e, dT.e);
+    law_Dd_pair(m, 0.5 * (cp.c + cp.s), 0.5 * (T.c + T.s), D.s, dT.s);
+    law_Dd_pair(m, 0.5 * (cp.n + cp.c), 0.5 * (T.n + T.c), D.n, dT.n);
 }
 TEDD_HD Face4 faces_dDd_dT(const ModelC& m, const St5& cp, const St5& T) {
     return Face4{law_dDd_dT(m, 0.5 * (cp.c + cp.w), 0.5 * (T.c + T.w)),
@@ -369,18 +386,24 @@ TEDD_HD double mms_fcl(const ModelC& m, const MmsPt& p) {
     return p.cl_t - (dDl * (p.cp_x * p.cl_x + p.cp_y * p.cl_y) + Dl * p.cl_l - law_V1(m, p.T) * p.cl_x -
                      (p.cl + 1.0) * (m.gamma_T * p.T_x) - m.K4 * p.cp * (p.cl + 1.0));
 }
+// gain = reaction_gain<REACT>(m, p.cs), shared by fcd and fcs
+TEDD_HD double mms_fcd_gain(const ModelC& m, const MmsPt& p, double gain) {
+    double Dd, dT;
+    law_Dd_pair(m, p.cp, p.T, Dd, dT);
+    const double dc = -m.phi_d * Dd;
+    return p.cd_t - ((dc * p.cp_x + dT * p.T_x) * p.cd_x + (dc * p.cp_y + dT * p.T_y) * p.cd_y + Dd * p.cd_l +
+                     m.Kd * (m.Sd - p.cd) * (p.cl + 1.0) * gain);
+}
+TEDD_HD double mms_fcs_gain(const ModelC& m, const MmsPt& p, double gain) {
+    return p.cs_t - (-m.Kd * gain * (1.0 + p.cl) * (m.Sd - p.cd));
+}
 template <int REACT>
 TEDD_HD double mms_fcd(const ModelC& m, const MmsPt& p) {
-    const double Te = p.T + m.T_shift;
-    const double Dd = law_Dd(m, p.cp, p.T);
-    const double dc = -m.phi_d * Dd;
-    const double dT = (Te != 0.0) ? Dd * tedd_div(tedd_div(m.phi_T, Te), Te) : 0.0;
-    return p.cd_t - ((dc * p.cp_x + dT * p.T_x) * p.cd_x + (dc * p.cp_y + dT * p.T_y) * p.cd_y + Dd * p.cd_l +
-                     m.Kd * (m.Sd - p.cd) * (p.cl + 1.0) * reaction_gain<REACT>(m, p.cs));
+    return mms_fcd_gain(m, p, reaction_gain<REACT>(m, p.cs));
 }
 template <int REACT>
 TEDD_HD double mms_fcs(const ModelC& m, const MmsPt& p) {
-    return p.cs_t - (-m.Kd * reaction_gain<REACT>(m, p.cs) * (1.0 + p.cl) * (m.Sd - p.cd));
+    return mms_fcs_gain(m, p, reaction_gain<REACT>(m, p.cs));
 }
 
 }  // namespace tedd

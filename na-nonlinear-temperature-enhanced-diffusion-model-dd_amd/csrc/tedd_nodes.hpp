@@ -71,8 +71,9 @@ TEDD_HD Forcing5 node_forcing(const ModelC& m, const MmsTabs& tb, const ForcingS
         const MmsPt p = mms_node<CASE>(m, src.tm, tb, li, j);
         r.fT = mms_fT(m, p);
         r.fcl = mms_fcl(m, p);
-        r.fcd = mms_fcd<REACT>(m, p);
-        r.fcs = mms_fcs<REACT>(m, p);
+        const double gain = reaction_gain<REACT>(m, p.cs);
+        r.fcd = mms_fcd_gain(m, p, gain);
+        r.fcs = mms_fcs_gain(m, p, gain);
         r.fcp = (interior && want_fcp) ? mms_fcp_cellavg<CASE>(m, src.tm, tb, li, j) : 0.0;
     }
     return r;
@@ -232,9 +233,10 @@ struct NewtonIn {
 // written so that  delta_c = (rhs + oe*d_e + ow*d_w + on*d_n + os*d_s) / diag.
 // For v = cd the reference assembles the (0,-1) coefficients on the (i-1,j) diagonal and the
 // (-1,0) ones on the (i,j-1) diagonal (prob1base.py:3097,3099); that is reproduced here.
+// D_pre (optional): the face diffusivities (Dl for cl, Dd for cd) if the caller already has them.
 template <int VAR, int REACT>
 TEDD_HD void newton_row(const ModelC& m, const GridDev& g, const NewtonIn& a, int li, int j, double dt,
-                        double& diag, double& oe, double& ow, double& on, double& os) {
+                        double& diag, double& oe, double& ow, double& on, double& os, const Face4* D_pre = nullptr) {
     const Geo ge = geo_at(g, li, j);
     const size_t c = at(g, li, j);
     Coef5 r;
@@ -246,10 +248,16 @@ TEDD_HD void newton_row(const ModelC& m, const GridDev& g, const NewtonIn& a, in
         T.c = 0.0; T.n = 0.0; T.s = 0.0;
         T.e = a.To[c + g.ld];
         T.w = a.To[c - g.ld];
-        r = jac_cl_Fcl(m, ge, faces_Dl(m, cp), T, cp.c, 1.0, 1.0);
+        r = jac_cl_Fcl(m, ge, D_pre ? *D_pre : faces_Dl(m, cp), T, cp.c, 1.0, 1.0);
     } else {
-        const St5 cp = load5(a.cp1, g, li, j), T = load5(a.To, g, li, j);
-        r = jac_cd_Fcd<REACT>(m, ge, faces_Dd(m, cp, T), a.clo[c], a.cs1[c]);
+        Face4 D;
+        if (D_pre) {
+            D = *D_pre;
+        } else {
+            const St5 cp = load5(a.cp1, g, li, j), T = load5(a.To, g, li, j);
+            D = faces_Dd(m, cp, T);
+        }
+        r = jac_cd_Fcd<REACT>(m, ge, D, a.clo[c], a.cs1[c]);
         const double t = r.w;  // reference quirk: W and S coefficients exchanged in the cd matrix
         r.w = r.s;
         r.s = t;
@@ -265,9 +273,10 @@ TEDD_HD void newton_row(const ModelC& m, const GridDev& g, const NewtonIn& a, in
 // 3068-3073, 3102-3108): rhs_T = Y_T - (2 T - dt F_T(S',t1)); rhs_cl = Y_cl - 2 cl + dt F_cl(S',t1)
 // + dt (dFcl/dT)(Tn - T); rhs_cd = Y_cd - 2 cd + dt F_cd(S',t1) + dt (dFcd/dT)(Tn - T)
 // + dt (dFcd/dcl)(cln - cl).
+// D_out (optional): receives the face diffusivities the right-hand side evaluated (cl, cd).
 template <int VAR, int CASE, int REACT>
 TEDD_HD double newton_rhs_value(const GridDev& g, const ModelC& m, const MmsTabs& tb, const ForcingSrc& f1,
-                                const NewtonIn& a, double dt, int li, int j) {
+                                const NewtonIn& a, double dt, int li, int j, Face4* D_out = nullptr) {
     const size_t c = at(g, li, j);
     const Geo ge = geo_at(g, li, j);
     double fv;
@@ -283,7 +292,9 @@ TEDD_HD double newton_rhs_value(const GridDev& g, const ModelC& m, const MmsTabs
         r = a.YT[c] - (2.0 * T.c - dt * (fv + rhs_T(m, ge, T, a.cp1[c])));
     } else if (VAR == VAR_CL) {
         const St5 cp = load5(a.cp1, g, li, j), T = load5(a.To, g, li, j), cl = load5(a.clo, g, li, j);
-        const double F = fv + rhs_cl(m, ge, faces_Dl(m, cp), T, cl, cp.c);
+        const Face4 Dl = faces_Dl(m, cp);
+        if (D_out) *D_out = Dl;
+        const double F = fv + rhs_cl(m, ge, Dl, T, cl, cp.c);
         // coupling  dt * (dFcl/dT) (Tn - To), boundary entries of (Tn - To) dropped
         const int i = g.i0 + li;
         const double w_ok = (i > 1) ? 1.0 : 0.0, e_ok = (i < g.N - 1) ? 1.0 : 0.0;
@@ -293,9 +304,12 @@ TEDD_HD double newton_rhs_value(const GridDev& g, const ModelC& m, const MmsTabs
     } else {
         const St5 cp = load5(a.cp1, g, li, j), T = load5(a.To, g, li, j), cd = load5(a.cdo, g, li, j);
         const double clc = a.clo[c], csc = a.cs1[c];
-        const double F = fv + rhs_cd_diffusion(ge, faces_Dd(m, cp, T), cd) + reaction<REACT>(m, clc, cd.c, csc);
+        Face4 Dd, dDd;
+        faces_Dd_pair(m, cp, T, Dd, dDd);
+        if (D_out) *D_out = Dd;
+        const double F = fv + rhs_cd_diffusion(ge, Dd, cd) + reaction<REACT>(m, clc, cd.c, csc);
         // coupling with (Tn - To) keeps the boundary entries of the increment
-        const Coef5 k = jac_T_Fcd(ge, faces_dDd_dT(m, cp, T), cd);
+        const Coef5 k = jac_T_Fcd(ge, dDd, cd);
         const St5 Tn = load5(a.Tn, g, li, j);
         const double JTw = k.c * (Tn.c - T.c) + k.e * (Tn.e - T.e) + k.w * (Tn.w - T.w) + k.n * (Tn.n - T.n) +
                            k.s * (Tn.s - T.s);
@@ -324,9 +338,10 @@ struct NewtonRhsFn {
             d1[c] = 0.0;
             return;
         }
-        const double r = newton_rhs_value<VAR, CASE, REACT>(g, m, tb, f1, a, dt, li, j);
+        Face4 D;
+        const double r = newton_rhs_value<VAR, CASE, REACT>(g, m, tb, f1, a, dt, li, j, &D);
         double diag, oe, ow, on, os;
-        newton_row<VAR, REACT>(m, g, a, li, j, dt, diag, oe, ow, on, os);
+        newton_row<VAR, REACT>(m, g, a, li, j, dt, diag, oe, ow, on, os, VAR == VAR_T ? nullptr : &D);
         if (rhs) rhs[c] = r;  // not needed by solvers that iterate on rhs/diag
         d1[c] = tedd_div(r, diag);
     }
