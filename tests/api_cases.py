@@ -82,6 +82,37 @@ def check_published_errors(case_name, levels, rel):
     return out
 
 
+SCALARS = json.load(open(os.path.join(GOLDEN, "golden_scalars.json")))
+
+
+def check_reference_run_errors(case_name, max_n, rel):
+    """MMSTrial.run_for_errors summaries of the reference itself (tests/golden/make_golden.py --scalars),
+    all 16 digits: the same spatial-study schedule as the notebooks."""
+    cls, mset, Tf = CASES[case_name]
+    ref = SCALARS[case_name]
+    assert ref["Tf"] == Tf and ref["model_set"] == mset
+    model = model_of(mset)
+    for lev in ref["levels"]:
+        N = lev["N"]
+        if N > max_n:
+            continue
+        summ = reg_trial(cls, model, N).run_for_errors(Tf=Tf, dt=(1.0 / N) ** 1.5)
+        assert summ.dt_used == pytest.approx(lev["dt_used"], rel=1e-15), (case_name, N)
+        assert summ.overall_combined_error == pytest.approx(lev["overall"], rel=rel), (case_name, N)
+        for v, val in lev["per_variable"].items():
+            # errors far below the O(1) fields carry the rounding of the fields themselves (~1e-16 absolute)
+            assert summ.per_variable_sup_errors[v] == pytest.approx(val, rel=10 * rel, abs=1e-15), (case_name, N, v)
+
+
+def check_reference_temporal_study(rel):
+    """The notebooks' temporal study for ExpSin (N=32, Tf=0.01, dt = 1e-2 / 2^i) run with the reference."""
+    cls, mset, _ = CASES["expsin"]
+    model = model_of(mset)
+    for row in SCALARS["expsin_temporal_N32"]:
+        summ = reg_trial(cls, model, 32).run_for_errors(Tf=0.01, dt=row["dt"])
+        assert summ.overall_combined_error == pytest.approx(row["overall"], rel=rel), row["dt"]
+
+
 def check_fused_equals_stepwise(case_name, N, nsteps_Tf):
     """The device-fused time loop + norms and the reference's step-by-step loop agree."""
     cls, mset, _ = CASES[case_name]

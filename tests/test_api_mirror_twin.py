@@ -25,6 +25,11 @@ def test_published_notebook_errors(case, levels, rel):
     ac.check_published_errors(case, levels, rel)
 
 
+@pytest.mark.parametrize("case,max_n", [("expsin", 32), ("pol", 16), ("peaks_fast1e1", 8), ("nfs_h2_h3", 8)])
+def test_error_norms_of_reference_runs(case, max_n):
+    ac.check_reference_run_errors(case, max_n, 2e-9)
+
+
 @pytest.mark.parametrize("case", ["expsin", "pol", "peaks_fast1e1", "nfs_h2_h3"])
 def test_fused_loop_equals_stepwise_loop(case):
     ac.check_fused_equals_stepwise(case, 8, 6)

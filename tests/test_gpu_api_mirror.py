@@ -31,6 +31,16 @@ def test_published_notebook_errors(case, levels, rel):
     ac.check_published_errors(case, levels, rel)
 
 
+@pytest.mark.parametrize("case,max_n", [("expsin", 128), ("pol", 128), ("peaks_fast1e1", 64), ("nfs_h2_h3", 64)])
+def test_error_norms_of_reference_runs(case, max_n):
+    # relative 2e-9: Jacobi to 1e-13 instead of SuperLU, summed over up to 4096 steps
+    ac.check_reference_run_errors(case, max_n, 2e-9)
+
+
+def test_temporal_study_of_reference_runs():
+    ac.check_reference_temporal_study(2e-9)
+
+
 @pytest.mark.parametrize("case", ["expsin", "pol", "peaks_fast1e1", "nfs_h2_h3"])
 def test_fused_loop_equals_stepwise_loop(case):
     ac.check_fused_equals_stepwise(case, 16, 10)
