@@ -47,7 +47,11 @@ enum tedd_mms_case {
 
 enum tedd_reaction {
     TEDD_REACT_CSTRIPLE = 0,    /* src/prob1base.py:2842-2876 */
-    TEDD_REACT_REGHCSTRIPLE = 1 /* src/prob1base.py:3553-3593 */
+    TEDD_REACT_REGHCSTRIPLE = 1,/* src/prob1base.py:3553-3593 */
+    TEDD_REACT_HCSTRIPLE = 2    /* src/prob1base.py:3298-3337: sharp Heaviside H(cs) = (cs > 0); the cs corrector
+                                   is the sign-case solve of :3376-3430, whose ValueError ("Denominator ... below
+                                   positiveness treshold") is reported as TEDD_ERR_INVALID by tedd_get_stats /
+                                   tedd_advance, the first calls that synchronise after the step */
 };
 
 typedef struct tedd_config {

@@ -79,7 +79,7 @@ public:
     double* d_red = nullptr;      // 64 doubles
     double* d_series = nullptr;   // error-norm series of tedd_advance
     size_t series_cap = 0;
-    int* d_ints = nullptr;        // [0] cs iterations kept
+    int* d_ints = nullptr;        // [0] cs iterations kept, [1] HCsTriple corrector: denominator not positive
 
     // record of the last PC step (for residuals and stats)
     struct LastStep {
@@ -109,7 +109,7 @@ public:
         if (c.row_lo < 0 || c.row_hi > N + 1 || c.row_lo >= c.row_hi) throw InvalidError("bad row range");
         if (c.ghost < 0) throw InvalidError("ghost < 0");
         if (c.model_kind != 1 && c.model_kind != 2) throw InvalidError("model_kind must be 1 or 2");
-        if (c.reaction_kind != REACT_CS3 && c.reaction_kind != REACT_REG) throw InvalidError("bad reaction_kind");
+        if (c.reaction_kind != REACT_CS3 && c.reaction_kind != REACT_REG && c.reaction_kind != REACT_HCS) throw InvalidError("bad reaction_kind");
         if (c.mms_case < CASE_STREAM || c.mms_case > CASE_NFS) throw InvalidError("bad mms_case");
         xg.assign(x, x + N + 1);
         yg.assign(y, y + M + 1);
@@ -403,14 +403,19 @@ public:
     }
         TEDD_D(CASE_STREAM, REACT_CS3)
         TEDD_D(CASE_STREAM, REACT_REG)
+        TEDD_D(CASE_STREAM, REACT_HCS)
         TEDD_D(CASE_POL, REACT_CS3)
         TEDD_D(CASE_POL, REACT_REG)
+        TEDD_D(CASE_POL, REACT_HCS)
         TEDD_D(CASE_EXPSIN, REACT_CS3)
         TEDD_D(CASE_EXPSIN, REACT_REG)
+        TEDD_D(CASE_EXPSIN, REACT_HCS)
         TEDD_D(CASE_PEAKS, REACT_CS3)
         TEDD_D(CASE_PEAKS, REACT_REG)
+        TEDD_D(CASE_PEAKS, REACT_HCS)
         TEDD_D(CASE_NFS, REACT_CS3)
         TEDD_D(CASE_NFS, REACT_REG)
+        TEDD_D(CASE_NFS, REACT_HCS)
 #undef TEDD_D
         throw InvalidError("unsupported case/reaction combination");
     }
@@ -539,7 +544,10 @@ public:
         Out5 o;
         for (int v = 0; v < 5; ++v) o.v[v] = tmp.p[v];
         Range r = need({{cur[0], true}, {cur[1], true}, {cur[2], true}, {cur[3], true}, {cur[4], false}});
-        if (react == REACT_REG) {
+        if (react == REACT_HCS) {
+            JacobianFn<REACT_HCS> f{grid(), model, fields(cur), o, opid};
+            be.nodes(FAM_MISC, f, r.lo, r.hi, ncols);
+        } else if (react == REACT_REG) {
             JacobianFn<REACT_REG> f{grid(), model, fields(cur), o, opid};
             be.nodes(FAM_MISC, f, r.lo, r.hi, ncols);
         } else {
@@ -1095,6 +1103,14 @@ public:
             s->increment[v] = red[2 * v + 1];
         }
         s->cs_iterations = last.cs_newton_ran ? ints[0] : 0;
+        raise_corrector_flag(ints[1]);
+    }
+    // The reference raises ValueError inside step() (prob1base.py:3406-3409); the device records the
+    // condition and the first call that synchronises reports it.
+    void raise_corrector_flag(int flag) {
+        if (flag == 0) return;
+        be.memset0(d_ints + 1, sizeof(int));
+        throw InvalidError("Denominator 2 - dt Kd (Sd - Cd1) (1 + Cl1) below positiveness treshold.");
     }
 
     // ------------------------------------------------------------------ multi-step with fused norms
@@ -1122,7 +1138,10 @@ public:
             if (series) error_norms_async(t, d_series + (size_t)(k + 1) * 8);
         }
         if (series) be.d2h(series, d_series, need_elems * sizeof(double));
+        int flag = 0;
+        if (react == REACT_HCS) be.d2h(&flag, d_ints + 1, sizeof(int));
         be.sync();
+        raise_corrector_flag(flag);
     }
 };
 

@@ -234,15 +234,22 @@ __global__ void k_cs_decide(const unsigned long long* gmax, const unsigned long 
     out_keep[0] = keep;
 }
 
-// closed-form correctors (CsTriple): plain node functor
+// closed-form correctors (CsTriple: trapezoid; HCsTriple: sign cases): plain node functor
 template <int CASE, int REACT>
 struct CorrectClosedFn {
     CorrectIn<CASE, REACT> a;
     double *cp_out, *cs_out;
+    int* bad_flag;  // set to 1 where the HCsTriple corrector's denominator is not positive
     __device__ void operator()(int li, int j) const {
         const size_t c = at(a.g, li, j);
         cp_out[c] = corrector_cp(a, li, j);
-        cs_out[c] = corrector_cs_closed_form(a, li, j);
+        if (REACT == REACT_HCS) {
+            bool bad = false;
+            cs_out[c] = corrector_cs_sign_case(a, li, j, &bad);
+            if (bad) *bad_flag = 1;
+        } else {
+            cs_out[c] = corrector_cs_closed_form(a, li, j);
+        }
     }
 };
 
@@ -450,8 +457,8 @@ struct HipBackend {
                  double rtol, int* d_keep) {
         check_range(r0, r1, ncols);
         if (r1 == r0) return;
-        if constexpr (REACT == REACT_CS3) {
-            CorrectClosedFn<CASE, REACT> f{a, cp_out, cs_out};
+        if constexpr (REACT != REACT_REG) {
+            CorrectClosedFn<CASE, REACT> f{a, cp_out, cs_out, d_keep + 1};
             nodes(FAM_CORRECT, f, r0, r1, ncols);
         } else {
             Scope sc(this, FAM_CS_NEWTON);

@@ -5,7 +5,7 @@
 //
 // Reference semantics restated here (file:line into the reference's src/):
 //   model laws            prob1base.py:96-217
-//   reaction term         prob1base.py:2489-2509, 3452-3466, 3592-3593, 2875-2876
+//   reaction term         prob1base.py:2489-2509, 3452-3466, 3592-3593, 2875-2876, 3336-3337
 //   F* right-hand sides   prob1base.py:2599-2672
 //   Jacobian stencils     prob1base.py:2511-2597, 2674-2839
 //   MMS forcing           prob1base.py:2313-2425, 3503-3551
@@ -23,7 +23,7 @@
 namespace tedd {
 
 enum : int { CASE_STREAM = -1, CASE_POL = 0, CASE_EXPSIN = 1, CASE_PEAKS = 2, CASE_NFS = 3 };
-enum : int { REACT_CS3 = 0, REACT_REG = 1 };
+enum : int { REACT_CS3 = 0, REACT_REG = 1, REACT_HCS = 2 };
 enum : int { VAR_CP = 0, VAR_T = 1, VAR_CL = 2, VAR_CD = 3, VAR_CS = 4 };
 
 constexpr double kPi = 3.14159265358979323846;
@@ -96,6 +96,7 @@ TEDD_HD double heaviside_reg(double x, double eta) { return tedd_div(1.0, 1.0 + 
 template <int REACT>
 TEDD_HD double reaction_gain(const ModelC& m, double cs) {
     if (REACT == REACT_REG) return heaviside_reg(cs, m.eta);
+    if (REACT == REACT_HCS) return (cs > 0.0) ? 1.0 : 0.0;  // sharp Heaviside, prob1base.py:3336-3337
     return cs;
 }
 // R = Kd g(cs) (1+cl) (Sd-cd)   (interior nodes only; callers apply the mask)

@@ -157,6 +157,7 @@ struct PredictFn {
     // the parts of the correctors that depend on the t0 state and the forcing only:
     // ncp = (1 + dt/2 al0) cp0 + dt/2 (fcp0 + fcp1)           (prob1base.py:2967-2996)
     // ycs = 2 cs0 - dt R(S0) + dt (fcs0 + fcs1)   (RegHCsTriple, prob1base.py:3665-3702)
+    //     = 2 cs0 + dt Fcs(S0,t0) + dt fcs1         (HCsTriple, prob1base.py:3376-3430)
     //     = (1 + dt/2 b0) cs0 + dt/2 (fcs0 + fcs1)    (CsTriple, prob1base.py:3190-3219)
     double *ncp, *ycs;
     TEDD_HD void operator()(int li, int j) const {
@@ -204,13 +205,15 @@ struct PredictFn {
         const double css = cs0 + dt * F.cs;
         const double Fcss = in ? (fcs1 - reaction<REACT>(m, cl0, cd0, css)) : 0.0;
         const double v = cs0 + (0.5 * dt) * (F.cs + Fcss);
-        cs1[c] = (REACT == REACT_REG) ? (in ? v : 0.0 * v) : v;
+        cs1[c] = (REACT != REACT_CS3) ? (in ? v : 0.0 * v) : v;  // RegHCs/HCs: times the interior mask (:3645, :3374)
         // corrector inputs
         const double h = dt / 2;
         const double al0 = -m.K2 * T0 - m.K1 * (cl0 + 1.0);
         ncp[c] = in ? (1.0 + h * al0) * cp0 + h * (fa.fcp + fcp1) : 0.0;
         if (REACT == REACT_REG) {
             ycs[c] = 2.0 * cs0 - dt * m.Kd * (m.Sd - cd0) * (cl0 + 1.0) * heaviside_reg(cs0, m.eta) + dt * (fa.fcs + fcs1);
+        } else if (REACT == REACT_HCS) {
+            ycs[c] = 2.0 * cs0 + dt * F.cs + dt * fcs1;  // Y0 of the sign-case corrector (:3412)
         } else {
             const double b0 = -m.Kd * (m.Sd - cd0) * (1.0 + cl0);
             ycs[c] = in ? (1.0 + h * b0) * cs0 + h * (fa.fcs + fcs1) : 0.0;
@@ -487,6 +490,24 @@ TEDD_HD double corrector_cs_closed_form(const CorrectIn<CASE, REACT>& a, int li,
     const double h = a.dt / 2;
     const double b1 = -m.Kd * (m.Sd - a.cd1[c]) * (1.0 + a.cl1[c]);
     return tedd_div(a.ycs[c], 1.0 - h * b1);
+}
+
+// HCsTriple: 2 cs1 - dt R1 H(cs1) = Y0 with R1 = Kd (Sd - cd1)(1 + cl1) solved by the sign of Y0
+// (prob1base.py:3376-3430).  *bad is set where 2 - dt R1 is not safely positive (the reference raises
+// ValueError then); evaluated on every node, result masked to the interior like the reference.
+template <int CASE, int REACT>
+TEDD_HD double corrector_cs_sign_case(const CorrectIn<CASE, REACT>& a, int li, int j, bool* bad) {
+    const size_t c = at(a.g, li, j);
+    const ModelC& m = a.m;
+    const double tol = 2.220446049250313e-16 * 100;
+    const double R1 = (m.Sd - a.cd1[c]) * (1.0 + a.cl1[c]) * m.Kd;
+    const double del = 2.0 - a.dt * R1;
+    if (del < tol) *bad = true;
+    const double Y0 = a.ycs[c];
+    double v = 0.0;
+    if (Y0 > tol) v = tedd_div(Y0, del);
+    else if (Y0 < -tol) v = Y0 / 2.0;
+    return is_interior(a.g, li, j) ? v : 0.0 * v;
 }
 
 // y and a of  2x + (2x - y) e^{-eta x} = y - a   (all nodes, boundary included)

@@ -18,7 +18,7 @@ CONST_NAMES = ("R0", "Ea", "K1", "K2", "K3", "K4", "DT", "Dl_max", "phi_l", "gam
                "Kd", "Sd", "Dd_max", "phi_d", "phi_T", "r_sp", "T_ref")
 
 MMS_STREAM, MMS_POL, MMS_EXPSIN, MMS_PEAKS, MMS_NFS = -1, 0, 1, 2, 3
-REACT_CSTRIPLE, REACT_REGHCSTRIPLE = 0, 1
+REACT_CSTRIPLE, REACT_REGHCSTRIPLE, REACT_HCSTRIPLE = 0, 1, 2
 
 _dptr = C.POINTER(C.c_double)
 _i32ptr = C.POINTER(C.c_int32)

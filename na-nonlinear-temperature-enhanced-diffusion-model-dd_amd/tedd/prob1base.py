@@ -635,6 +635,15 @@ class ForcingTerms_CsTriple(_DeviceForcingTerms):
         super().__init__(mms_case=mms_case, model=model, eta=0.0)
 
 
+class ForcingTerms_HCsTriple(_DeviceForcingTerms):
+    """Forcing with the sharp Heaviside H(cs) = (cs > 0) in fcd, fcs (reference src/prob1base.py:3222-3295)."""
+
+    reaction_kind = _ffi.REACT_HCSTRIPLE
+
+    def __init__(self, *, mms_case: MMSCaseBase, model: DefaultModel01):
+        super().__init__(mms_case=mms_case, model=model, eta=0.0)
+
+
 class ForcingTerms_RegHCsTriple(_DeviceForcingTerms):
     reaction_kind = _ffi.REACT_REGHCSTRIPLE
 
@@ -799,6 +808,15 @@ class SemiDiscreteField_CsTriple(_DeviceField):
     """[Cs-Cd-int] = Kd (Sd - Cd)(1 + Cl) Cs   (reference src/prob1base.py:2842-2876)."""
 
     reaction_kind = _ffi.REACT_CSTRIPLE
+
+    def __init__(self, *, grid: Grid, model: DefaultModel01, forcing_terms: ForcingTermsBase):
+        super().__init__(grid=grid, model=model, forcing_terms=forcing_terms, eta=0.0)
+
+
+class SemiDiscreteField_HCsTriple(_DeviceField):
+    """[Cs-Cd-int] = Kd (Sd - Cd)(1 + Cl) H(Cs), H(cs) = (cs > 0)   (reference src/prob1base.py:3298-3337)."""
+
+    reaction_kind = _ffi.REACT_HCSTRIPLE
 
     def __init__(self, *, grid: Grid, model: DefaultModel01, forcing_terms: ForcingTermsBase):
         super().__init__(grid=grid, model=model, forcing_terms=forcing_terms, eta=0.0)
@@ -991,6 +1009,19 @@ class P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_CsTriple(P_ModifiedEuler_C_Tr
     """CsTriple variant: closed-form trapezoidal corrector for cs (reference src/prob1base.py:3152-3219)."""
 
     _reaction_kind = _ffi.REACT_CSTRIPLE
+
+    def __init__(self, semi_discrete_field, *, num_pc_steps=1, num_newton_steps=1, **device_kwargs):
+        super().__init__(semi_discrete_field, num_pc_steps=num_pc_steps, num_newton_steps=num_newton_steps,
+                         **device_kwargs)
+
+
+class P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_HCsTriple(P_ModifiedEuler_C_Trapezoidal_TimeIntegratorBase):
+    """HCsTriple variant: Heun predictor for cs times the interior mask; cs corrector by the sign of
+    Y0 = 2 cs0 + dt Fcs(S0, t0) + dt fcs1 (cs1 = Y0 / (2 - dt R1) if Y0 > 0, Y0 / 2 if Y0 < 0, else 0),
+    raising ValueError when 2 - dt Kd (Sd - cd1)(1 + cl1) is not positive  (reference
+    src/prob1base.py:3340-3430)."""
+
+    _reaction_kind = _ffi.REACT_HCSTRIPLE
 
     def __init__(self, semi_discrete_field, *, num_pc_steps=1, num_newton_steps=1, **device_kwargs):
         super().__init__(semi_discrete_field, num_pc_steps=num_pc_steps, num_newton_steps=num_newton_steps,

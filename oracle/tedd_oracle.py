@@ -92,9 +92,11 @@ def heaviside_reg(x, eta):  # src/prob1base.py:3452-3466
 
 def reaction_gain(cs, react, eta):
     """g(cs) in R = Kd g(cs) (1+cl) (Sd-cd): H_eta for 'reg' (:3592-3593), identity for
-    'cs3' (:2875-2876)."""
+    'cs3' (:2875-2876), the sharp Heaviside (cs > 0) for 'hcs' (:3336-3337)."""
     if react == "reg":
         return heaviside_reg(cs, eta)
+    if react == "hcs":
+        return (cs > 0).astype(float)
     if react == "cs3":
         return cs
     raise ValueError(react)
@@ -631,7 +633,7 @@ class Problem:
     mesh: Mesh
     model: Model
     case: MMSCase | None
-    react: str = "reg"       # "reg" (RegHCsTriple) or "cs3" (CsTriple)
+    react: str = "reg"       # "reg" (RegHCsTriple), "cs3" (CsTriple) or "hcs" (HCsTriple)
     eta: float = 50.0
 
     def forcing(self, t):
@@ -687,7 +689,7 @@ def step_pc(pb, S0, t0, dt, *, num_pc_steps=1, num_newton_steps=1, num_newton_it
     cs_star = S0["cs"] + dt * F0["cs"]
     Fcs_star = field_Fcs(mesh, m, dict(S0, cs=cs_star), f1, react, eta)
     cs1 = S0["cs"] + (0.5 * dt) * (F0["cs"] + Fcs_star)
-    if react == "reg":
+    if react in ("reg", "hcs"):                                       # :3645, :3374
         cs1 = cs1 * mask
 
     T1, cl1, cd1 = S0["T"], S0["cl"], S0["cd"]
@@ -732,6 +734,17 @@ def step_pc(pb, S0, t0, dt, *, num_pc_steps=1, num_newton_steps=1, num_newton_it
                  + dt * (f0["fcs"] + f1["fcs"]))
             a = dt * m.Kd * (m.Sd - cd1) * (cl1 + 1)
             cs1 = cs_newton(y, a, eta, S0["cs"], num_newton_iterations, consec_xs_rtol) * mask
+        elif react == "hcs":                                          # :3376-3430
+            tol = np.finfo(float).eps * 100
+            del_Y1 = 2 - dt * (m.Sd - cd1) * (1 + cl1) * m.Kd
+            if np.any(del_Y1 < tol):
+                raise ValueError("Denominator 2 - dt Kd (Sd - Cd1) (1 + Cl1) below positiveness treshold.")
+            Y0 = 2 * S0["cs"] + dt * F0["cs"] + dt * f1["fcs"]
+            cs1 = mesh.zeros()
+            pos, neg = Y0 > tol, Y0 < -tol
+            cs1[pos] = Y0[pos] / del_Y1[pos]
+            cs1[neg] = Y0[neg] / 2.0
+            cs1 = cs1 * mask
         else:                                                         # :3190-3219
             b0 = -m.Kd * (m.Sd - S0["cd"][it]) * (1 + S0["cl"][it])
             b1 = -m.Kd * (m.Sd - cd1[it]) * (1 + cl1[it])

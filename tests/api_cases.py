@@ -250,6 +250,72 @@ def check_newton_residuals(case_name, N=8, dt=1e-4, steps=(1, 20)):
                 assert grid.norm_H(integ.last_residual[v]) < 1e-9, (case_name, k, v)
 
 
+def check_hcs_newton_residuals(case_name, steps=(1, 20)):
+    """reference tests/test_newton_residuals.py:127-198: ||last_residual||_H < 1e-9 after 1 and 20 steps
+    of the HCsTriple integrator with 5 Newton steps (N=8, dt=1e-4, its model constants)."""
+    cls = CASES[case_name][0]
+    mc = p1.default_model_consts._replace(K1=1e-2, K2=1e-2, K3=1e-2, K4=1e-2, DT=1e-3, Kd=1e-3, Sd=10)
+    model = p1.DefaultModel02(mc=mc)
+    grid = p1.make_uniform_grid(8, 8)
+    case = cls(grid=grid, model=model)
+    field = p1.SemiDiscreteField_HCsTriple(grid=grid, model=model,
+                                           forcing_terms=p1.ForcingTerms_HCsTriple(mms_case=case, model=model))
+    integ = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_HCsTriple(field, num_pc_steps=1, num_newton_steps=5)
+    S = p1.state_from_mms_when(mms_case=case, t=0.0, grid=grid)
+    t, dt = 0.0, 1e-4
+    for k in range(1, max(steps) + 1):
+        S = integ.step(S, t0=t, dt=dt)
+        t += dt
+        if k in steps:
+            for v in ("T", "cl", "cd"):
+                assert grid.norm_H(integ.last_residual[v]) < 1e-9, (case_name, k, v)
+
+
+def check_hcs_cs_ramp_single_step(cs_initial, cs_slope, dt=0.01):
+    """reference tests/test_time_integrator_hcs_triple_full_step.py:133-283: cp = T = cl = cd = 0 and
+    cs = (cs_initial + cs_slope t) x(1-x) y(1-y); one step reproduces the exact solution (the ramp is
+    linear in t, the corrector is exact for it) whatever the sign of cs before and after the step.
+    The manufactured forcing is supplied as host arrays (streamed to the device)."""
+    mc = p1.ModelConsts(R0=8.3144621, Ea=1.60217662e-19, K1=1.52e-2, K2=1.52e-2, K3=1.52e-2, K4=1.52e-2,
+                        DT=1.22e-3, Dl_max=8.22e-4, phi_l=1.22e-5, gamma_T=1.22e-9, Kd=1.22e-8, Sd=15,
+                        Dd_max=2.62e-6, phi_d=1.22e-5, phi_T=1.60217662e-19 / 8.3144621, r_sp=5.22e-2, T_ref=303)
+    model = p1.DefaultModel01(mc=mc)
+    grid = p1.make_uniform_grid(N=4, M=4)
+    P = grid.xx * (1 - grid.xx) * grid.yy * (1 - grid.yy)
+    zero = grid.make_full0()
+
+    def cs_exact(t):
+        return (cs_initial + cs_slope * t) * P
+
+    forcing = p1.ForcingTermsFromDict({
+        "fcp": lambda t, xx, yy: zero.copy(), "fT": lambda t, xx, yy: zero.copy(),
+        "fcl": lambda t, xx, yy: zero.copy(),
+        "fcd": lambda t, xx, yy: -mc.Kd * mc.Sd * (cs_exact(t) > 0),
+        "fcs": lambda t, xx, yy: cs_slope * P + mc.Kd * mc.Sd * (cs_exact(t) > 0)})
+    field = p1.SemiDiscreteField_HCsTriple(grid=grid, model=model, forcing_terms=forcing)
+    integ = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_HCsTriple(field, num_pc_steps=1, num_newton_steps=1)
+    S0 = p1.StateVars(zero.copy(), zero.copy(), zero.copy(), zero.copy(), cs_exact(0.0), model=model,
+                      hh=grid.hh, kk=grid.kk)
+    S1 = integ.step(S0, t0=0.0, dt=dt)
+    for v in ("cp", "T", "cl", "cd"):
+        np.testing.assert_allclose(getattr(S1, v), zero, rtol=1e-8, atol=1e-12, err_msg=v)
+    np.testing.assert_allclose(S1.cs, cs_exact(dt), rtol=1e-6, atol=1e-12)
+
+
+def check_hcs_denominator_value_error():
+    """reference src/prob1base.py:3406-3409: step() raises ValueError when 2 - dt Kd (Sd - cd1)(1 + cl1)
+    is not positive."""
+    mc = p1.default_model_consts._replace(Kd=1e4)
+    model = p1.DefaultModel02(mc=mc)
+    grid = p1.make_uniform_grid(5, 5)
+    case = p1mc.MMSCasePol(grid=grid, model=model)
+    field = p1.SemiDiscreteField_HCsTriple(grid=grid, model=model,
+                                           forcing_terms=p1.ForcingTerms_HCsTriple(mms_case=case, model=model))
+    integ = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_HCsTriple(field, jacobi_sweeps=(50, 50, 50))
+    with pytest.raises(ValueError):
+        integ.step(p1.state_from_mms_when(mms_case=case, t=0.0, grid=grid), t0=0.0, dt=0.1)
+
+
 def check_error_behaviour():
     model = model_of("nb_a")
     trial = reg_trial(p1mc.MMSCaseExpSin, model, 4)

@@ -125,3 +125,95 @@ def run_steps(tag, options=None, **overrides):
     stats = ctx.get_stats() if is_pc else {}
     ctx.close()
     return worst, wres, stats
+
+
+# ---------------------------------------------------------------------------------- HCsTriple
+def check_ops_hcs(tag):
+    """F* and the six Jacobian stencils of the sharp-Heaviside field on a random state (cs of both
+    signs and an exact zero), zero forcing."""
+    z = load("golden_hcs.npz")
+    ctx = make_ctx(z, tag, _ffi.REACT_HCSTRIPLE, _ffi.MMS_STREAM)
+    S = [z[f"{tag}/{v}"] for v in VARS]
+    ctx.set_state(*S)
+    zero = np.zeros_like(S[0])
+    ctx.set_forcing(0, zero, zero, zero, zero, zero)
+    worst = 0.0
+    for v, a in zip(VARS, ctx.eval_field(0.3)):
+        worst = max(worst, relerr(a, z[f"{tag}/hcs/F{v}"]))
+    for op, name in enumerate(JAC_OPS):
+        J = ctx.eval_jacobian(op)
+        g = z[f"{tag}/hcs/{name}"]
+        sc = np.max(np.abs(g))
+        for n in range(5):
+            worst = max(worst, relerr(J[n], g[n], sc))
+    ctx.close()
+    return worst
+
+
+def check_mms_hcs(tag):
+    z = load("golden_hcs.npz")
+    cname = tag.split("/")[1]
+    ctx = make_ctx(z, tag, _ffi.REACT_HCSTRIPLE, CASE_ID[cname], CASE_PARAMS[cname])
+    worst = 0.0
+    for it in (0, 1):
+        t = float(z[f"{tag}/t{it}/t"])
+        fscale = max(1.0, np.max(np.abs(z[f"{tag}/t{it}/cp"])))
+        for v, a in zip(("fcp", "fT", "fcl", "fcd", "fcs"), ctx.eval_forcing(t)):
+            worst = max(worst, relerr(a, z[f"{tag}/t{it}/hcs/{v}"], fscale))
+    ctx.close()
+    return worst
+
+
+def run_steps_hcs(tag, options=None):
+    """Integrate a HCsTriple step fixture; same return values as run_steps."""
+    z = load("golden_hcs.npz")
+    kind = tag.split("/")[1]
+    cname = str(z[f"{tag}/case"]) if f"{tag}/case" in z.files else tag.split("/")[2]
+    ctx = make_ctx(z, tag, _ffi.REACT_HCSTRIPLE, CASE_ID[cname], CASE_PARAMS[cname])
+    for name, value in (options or {}).items():
+        ctx.set_option(name, value)
+    ctx.set_state(*[z[f"{tag}/s0/{v}"] for v in VARS])
+    t, dt = float(z[f"{tag}/t0"]), float(z[f"{tag}/dt"])
+    saved = sorted(int(k.split("/")[-2][1:]) for k in z.files
+                   if k.startswith(tag + "/s") and k.endswith("/cp") and "/s0/" not in k)
+    is_pc = kind.startswith("pc")
+    kw = {name: int(z[f"{tag}/{name}"]) for name in ("num_pc_steps", "num_newton_steps") if f"{tag}/{name}" in z.files}
+    worst, wres = 0.0, 0.0
+    for k in range(1, max(saved) + 1):
+        if is_pc:
+            ctx.step_pc(t, dt, cs_newton_iterations=0, **kw)
+        else:
+            ctx.step_feuler(t, dt)
+        t += dt
+        if k in saved:
+            out = ctx.get_state()
+            scale = max(np.max(np.abs(z[f"{tag}/s{k}/{v}"])) for v in VARS)
+            for v, a in zip(VARS, out):
+                worst = max(worst, np.max(np.abs(a - z[f"{tag}/s{k}/{v}"])) / scale)
+            if is_pc:
+                for v, a in zip(("T", "cl", "cd"), ctx.get_residuals()):
+                    wres = max(wres, np.max(np.abs(a - z[f"{tag}/s{k}/res_{v}"])))
+    stats = ctx.get_stats() if is_pc else {}
+    ctx.close()
+    return worst, wres, stats
+
+
+def check_hcs_denominator_error():
+    """A step whose corrector denominator 2 - dt Kd (Sd - cd1)(1 + cl1) is not positive: the library
+    reports ValueError at the first call that synchronises (the reference raises it inside step())."""
+    z = load("golden_hcs.npz")
+    tag = "steps/pc_hcs/pol/N5"
+    consts = np.array(z[f"{tag}/consts"])
+    consts[_ffi.CONST_NAMES.index("Kd")] = 1e4
+    ctx = _ffi.Context(z[f"{tag}/x"], z[f"{tag}/y"], consts, model_kind=2, reaction_kind=_ffi.REACT_HCSTRIPLE,
+                       eta=0.0, mms_case=_ffi.MMS_POL)
+    ctx.set_state_exact(0.0)
+    ctx.step_pc(0.0, 0.1, cs_newton_iterations=0, jacobi_sweeps=(50, 50, 50))
+    try:
+        ctx.get_stats()
+    except ValueError as e:
+        assert "positiveness" in str(e)
+    else:
+        raise AssertionError("no ValueError")
+    ctx.get_stats()  # the condition is reported once
+    ctx.close()

@@ -64,6 +64,13 @@ struct CpuBackend {
                 for (int j = 0; j < ncols; ++j) cs_out[at(a.g, li, j)] = corrector_cs_closed_form(a, li, j);
             return;
         }
+        if (REACT == REACT_HCS) {
+            bool bad = false;
+            for (int li = r0; li < r1; ++li)
+                for (int j = 0; j < ncols; ++j) cs_out[at(a.g, li, j)] = corrector_cs_sign_case(a, li, j, &bad);
+            if (bad) keep_out[1] = 1;
+            return;
+        }
         const size_t n = (size_t)(r1 - r0) * ncols;
         std::vector<double> x(n), y(n), av(n);
         size_t q = 0;

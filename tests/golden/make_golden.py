@@ -16,6 +16,8 @@ The fixtures are plain data (inputs + the reference's outputs, float64 .npz and
                       for the four configured MMS cases at two times
   golden_steps.npz    states after 1/2/5 integrator.step() calls (+ last_residual)
                       for forward Euler and the predictor-corrector integrators
+  golden_hcs.npz      the same three kinds of vectors for the HCsTriple (sharp Heaviside)
+                      field, forcing terms and predictor-corrector integrator
   golden_scalars.json MMSTrial.run_for_errors summaries (only with --scalars; slow)
   published_notebook_errors.json   numbers printed in the reference's executed
                       notebooks (parsed from the .ipynb stream outputs)
@@ -346,6 +348,113 @@ def gen_steps():
 
 
 # ----------------------------------------------------------------------------------
+def gen_hcs():
+    """HCsTriple: field / Jacobians on random states, forcing terms, integrator steps."""
+    out = {}
+    PC_HCS = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_HCsTriple
+    rng = np.random.default_rng(20250611)
+    # (a) field and Jacobian stencils, zero forcing, cs crossing zero
+    grids = {"u5x4": (np.linspace(0, 1, 6), np.linspace(0, 1, 5)),
+             "nu6x9": (nonuniform_axis(6, 1.3, 0.2), nonuniform_axis(9, 0.8, -0.15))}
+    for gname, (x, y) in grids.items():
+        grid = p1.Grid(x, y)
+        shp = (grid.N + 1, grid.M + 1)
+        for mname, kind in [("stress", 2), ("nb_a", 2)]:
+            tag = f"ops/{gname}/{mname}{kind}"
+            model = make_model(mname, kind)
+            S = {"cp": rng.random(shp) + 0.1, "T": rng.random(shp), "cl": rng.random(shp),
+                 "cd": rng.random(shp), "cs": rng.random(shp) * 0.2 - 0.05}
+            S["cs"][1, 1] = 0.0  # H(0) = 0
+            out[f"{tag}/x"], out[f"{tag}/y"] = x, y
+            out[f"{tag}/consts"] = consts_vec(mname)
+            out[f"{tag}/model_kind"] = np.array(kind)
+            out[f"{tag}/eta"] = np.array(0.0)
+            for v, a in S.items():
+                out[f"{tag}/{v}"] = a
+            state = p1.StateVars(S["cp"], S["T"], S["cl"], S["cd"], S["cs"], model=model, hh=grid.hh, kk=grid.kk)
+            field = p1.SemiDiscreteField_HCsTriple(grid=grid, model=model, forcing_terms=p1.NoForcingTerms(grid))
+            for v in ["cp", "T", "cl", "cd", "cs"]:
+                out[f"{tag}/hcs/F{v}"] = getattr(field, f"F{v}")(state, 0.3)
+            for opname in ["delT_ab_FT_ij", "delT_ab_Fcl_ij", "delcl_ab_Fcl_ij", "delT_ab_Fcd_ij",
+                           "delcl_ab_Fcd_ij", "delcd_ab_Fcd_ij"]:
+                fn = getattr(field, opname)
+                out[f"{tag}/hcs/{opname}"] = np.stack([fn(state, a=a, b=b) for a, b in OFFS])
+    # (b) forcing terms of the four configured cases at two times
+    x, y = np.linspace(0, 1, 7), nonuniform_axis(7, 0.9, -0.1)
+    for cname, (cls, mname) in MMS_CASES.items():
+        grid = p1.Grid(x, y)
+        model = make_model(mname, 2)
+        case = cls(grid=grid, model=model)
+        tag = f"mms/{cname}"
+        out[f"{tag}/x"], out[f"{tag}/y"] = x, y
+        out[f"{tag}/consts"] = consts_vec(mname)
+        out[f"{tag}/model_kind"] = np.array(2)
+        out[f"{tag}/eta"] = np.array(0.0)
+        f = p1.ForcingTerms_HCsTriple(mms_case=case, model=model)
+        for it, t in enumerate([0.0, 0.37]):
+            out[f"{tag}/t{it}/t"] = np.array(t)
+            out[f"{tag}/t{it}/cp"] = case.cp(t, grid.xx, grid.yy)
+            for v in ["fcp", "fT", "fcl", "fcd", "fcs"]:
+                out[f"{tag}/t{it}/hcs/{v}"] = getattr(f, v)(t, grid.xx, grid.yy)
+
+    def hcs_trial(cls, model, grid, integ, integ_params):
+        return mtu.MMSTrial(grid=grid, model=model, mms_case_cls=cls,
+                            field_cls=p1.SemiDiscreteField_HCsTriple,
+                            forcing_terms_cls=p1.ForcingTerms_HCsTriple,
+                            integrator_cls=integ, integrator_params=integ_params)
+
+    def put_common(tag, x, y, mname, extra=None):
+        out[f"{tag}/x"], out[f"{tag}/y"] = x, y
+        out[f"{tag}/consts"] = consts_vec(mname)
+        out[f"{tag}/model_kind"] = np.array(2)
+        out[f"{tag}/eta"] = np.array(0.0)
+        for k, v in (extra or {}).items():
+            out[f"{tag}/{k}"] = np.array(v)
+
+    # (c) predictor-corrector steps, dt = h^1.5
+    for cname, (cls, mname) in MMS_CASES.items():
+        for N in [5, 8, 16]:
+            xu = np.linspace(0, 1, N + 1)
+            tag = f"steps/pc_hcs/{cname}/N{N}"
+            put_common(tag, xu, xu, mname, dict(num_pc_steps=1, num_newton_steps=1))
+            trial = hcs_trial(cls, make_model(mname, 2), p1.Grid(xu, xu.copy()), PC_HCS, {})
+            _record_steps(out, tag, trial, 0.0, (1.0 / N) ** 1.5, [1, 2, 5], True)
+    # two Newton steps and two predictor-corrector iterations; a non-uniform mesh
+    xu = np.linspace(0, 1, 9)
+    for vname, ip in [("v_newton2", dict(num_newton_steps=2)), ("v_pc2", dict(num_pc_steps=2))]:
+        tag = f"steps/pc_hcs/{vname}"
+        params = dict(num_pc_steps=1, num_newton_steps=1)
+        params.update(ip)
+        put_common(tag, xu, xu, "nb_a", dict(params, case="expsin"))
+        trial = hcs_trial(p1mc.MMSCaseExpSin, make_model("nb_a", 2), p1.Grid(xu, xu.copy()), PC_HCS, ip)
+        _record_steps(out, tag, trial, 0.0, (1.0 / 8) ** 1.5, [1, 2, 5], True)
+    xn, yn = nonuniform_axis(6, 1.3, 0.2), nonuniform_axis(9, 0.8, -0.15)
+    tag = "steps/pc_hcs/nonuniform_pol"
+    put_common(tag, xn, yn, "stress", dict(num_pc_steps=1, num_newton_steps=1, case="pol"))
+    trial = hcs_trial(p1mc.MMSCasePol, make_model("stress", 2), p1.Grid(xn, yn), PC_HCS, {})
+    _record_steps(out, tag, trial, 0.0, 0.02, [1, 2, 5], True)
+    # cs of both signs and exact zeros at t0: all three branches of the sign-case corrector
+    xu = np.linspace(0, 1, 9)
+    tag = "steps/pc_hcs/v_signs"
+    put_common(tag, xu, xu, "nb_b", dict(num_pc_steps=1, num_newton_steps=1, case="pol"))
+    trial = hcs_trial(p1mc.MMSCasePol, make_model("nb_b", 2), p1.Grid(xu, xu.copy()), PC_HCS, {})
+    s0 = trial.initial_state
+    cs = s0.cs - 0.03
+    cs[2, :] = 0.0
+    trial.initial_state = s0.with_changes(cs=cs)
+    _record_steps(out, tag, trial, 0.0, (1.0 / 8) ** 1.5, [1, 2, 5], True)
+    # (d) forward Euler on the HCsTriple field
+    xu = np.linspace(0, 1, 6)
+    tag = "steps/fe_hcs/pol/N5"
+    put_common(tag, xu, xu, "nb_b")
+    trial = hcs_trial(p1mc.MMSCasePol, make_model("nb_b", 2), p1.Grid(xu, xu.copy()), p1.ForwardEulerIntegrator, {})
+    _record_steps(out, tag, trial, 0.0, (1.0 / 5) ** 1.5 * 0.1, [1, 3], False)
+
+    np.savez_compressed(os.path.join(HERE, "golden_hcs.npz"), **out)
+    print("golden_hcs.npz:", len(out), "arrays")
+
+
+# ----------------------------------------------------------------------------------
 def gen_scalars(max_n_short=128, max_n_long=32):
     """MMSTrial.run_for_errors known answers on the notebooks' spatial-study schedule."""
     PC_REG = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple
@@ -425,13 +534,15 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     np.seterr(all="ignore")
-    todo = a.only.split(",") if a.only else ["ops", "mms", "steps", "published"]
+    todo = a.only.split(",") if a.only else ["ops", "mms", "steps", "hcs", "published"]
     if "ops" in todo:
         gen_ops()
     if "mms" in todo:
         gen_mms()
     if "steps" in todo:
         gen_steps()
+    if "hcs" in todo:
+        gen_hcs()
     if "published" in todo:
         gen_published()
     if a.scalars:

@@ -79,3 +79,18 @@ def test_newton_residuals(case):
 
 def test_error_behaviour():
     ac.check_error_behaviour()
+
+
+# ---- HCsTriple (sharp Heaviside) through the mirrored classes
+@pytest.mark.parametrize("case", ["pol", "expsin", "peaks_fast1e1"])
+def test_hcs_newton_residuals(case):
+    ac.check_hcs_newton_residuals(case)
+
+
+@pytest.mark.parametrize("cs_initial,cs_slope", [(1.0, -0.5), (0.1, -10.0), (0.1, -15.0), (-0.2, -0.5), (0.0, -5.0)])
+def test_hcs_single_step_with_cs_ramp(cs_initial, cs_slope):
+    ac.check_hcs_cs_ramp_single_step(cs_initial, cs_slope)
+
+
+def test_hcs_corrector_value_error():
+    ac.check_hcs_denominator_value_error()

@@ -57,3 +57,25 @@ def test_integrator_steps(tag, solver):
     assert err < (2e-12 if "bigdt" in tag else 5e-14), (tag, err, stats)
     # Newton residuals: absolute (they are differences of O(1) quantities)
     assert res_err < 1e-13, (tag, res_err)
+
+
+# ---- HCsTriple (sharp Heaviside) field, forcing terms and predictor-corrector integrator
+@pytest.mark.parametrize("tag", cc.tags("golden_hcs.npz", "/hcs/Fcp"))
+def test_hcs_field_and_jacobian_stencils(tag):
+    assert cc.check_ops_hcs(tag) < 1e-13
+
+
+@pytest.mark.parametrize("tag", cc.tags("golden_hcs.npz", "/t0/hcs/fcp"))
+def test_hcs_forcing(tag):
+    assert cc.check_mms_hcs(tag) < 1e-13
+
+
+@pytest.mark.parametrize("tag", cc.tags("golden_hcs.npz", "/t0"))
+def test_hcs_integrator_steps(tag):
+    err, res_err, stats = cc.run_steps_hcs(tag)
+    assert err < 5e-14, (tag, err, stats)
+    assert res_err < 1e-13, (tag, res_err)
+
+
+def test_hcs_corrector_reports_nonpositive_denominator():
+    cc.check_hcs_denominator_error()
