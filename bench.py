@@ -65,12 +65,6 @@ def arrays_per_launch(solver, cache_forcing, sweeps, hmax):
             # every launch reads b and the coefficient fields and writes one array; launches after the
             # first also read the iterate; the last also reads the lagged unknown
             arr = sum(1 + coef[var] + (1 if l > 0 else 0) + (1 if l == L - 1 else 0) + 1 for l in range(L))
-        elif solver == "blocked":
-            single = {"T": 4, "cl": 6, "cd": 9}[var]
-            first = {"T": 5, "cl": 7, "cd": 10}[var]
-            middle = {"T": 4, "cl": 5, "cd": 7}[var]
-            last = {"T": 5, "cl": 6, "cd": 8}[var]
-            arr = single if L == 1 else first + (L - 2) * middle + last
         else:
             continue
         chains["solve_" + var] = {"launches_per_solve": L, "arrays_per_solve": arr}
@@ -81,8 +75,8 @@ def arrays_per_launch(solver, cache_forcing, sweeps, hmax):
 # kernel-name fragment of each launch family in the rocprofv3 counter files
 FAMILY_KERNELS = {"predict": ["PredictFn"], "forcing": ["ForcingFn"], "cs_newton": ["k_cs_newton"],
                   "rhs_T": ["NewtonRhsFn<1,"], "rhs_cl": ["NewtonRhsFn<2,"], "rhs_cd": ["NewtonRhsFn<3,"],
-                  "solve_T": ["k_solve_strip<1,", "k_solve_blocked<1,"], "solve_cl": ["k_solve_strip<2,", "k_solve_blocked<2,"],
-                  "solve_cd": ["k_solve_strip<3,", "k_solve_blocked<3,"]}
+                  "solve_T": ["k_solve_strip<1,"], "solve_cl": ["k_solve_strip<2,"], "solve_cd": ["k_solve_strip<3,"],
+                  "jacobi_T": ["JacobiFn<1,"], "jacobi_cl": ["JacobiFn<2,"], "jacobi_cd": ["JacobiFn<3,"]}
 
 
 def pmc_traffic(fam, config):
@@ -171,8 +165,8 @@ def main():
     ap.add_argument("--mesh", type=int, default=16384, help="N of the (N+1)^2-node synthetic mesh")
     ap.add_argument("--jacobi-tol", type=float, default=1e-13)
     ap.add_argument("--no-extras", action="store_true", help="skip the N=256 study-mesh and CPU-baseline legs")
-    ap.add_argument("--solver", choices=["strip", "blocked", "sweeps"], default="strip",
-                    help="Newton solve: register-resident chain | LDS-blocked chain | one launch per Jacobi sweep")
+    ap.add_argument("--solver", choices=["strip", "sweeps"], default="strip",
+                    help="Newton solve: register-resident chain | one launch per Jacobi sweep")
     ap.add_argument("--hmax", type=int, default=10, help="Jacobi sweeps fused per launch of a solve chain")
     ap.add_argument("--cache-forcing", type=int, default=1,
                     help="1: forcing arrays evaluated once per time level; 0: inside the step kernels")
@@ -205,9 +199,9 @@ def main():
                        mms_case=_ffi.MMS_EXPSIN, row_lo=slab.row_lo, row_hi=slab.row_hi, ghost=slab.ghost,
                        device=local_rank)
     stepper = SlabStepper(ctx, slab, device)
-    ctx.set_option("blocked_solve", {"strip": 2, "blocked": 1, "sweeps": 0}[args.solver])
+    ctx.set_option("strip_solve", 1 if args.solver == "strip" else 0)
     ctx.set_option("cache_forcing", args.cache_forcing)
-    ctx.set_option("blocked_hmax", args.hmax)
+    ctx.set_option("strip_hmax", args.hmax)
     for kv in args.opt:
         name, value = kv.split("=")
         ctx.set_option(name, float(value))

@@ -79,9 +79,11 @@ const char* tedd_last_error(const tedd_ctx* ctx); /* ctx may be NULL: error of t
  * place between steps, e.g. tests/test_time_integrator_hcs_triple.py:377-387). */
 int tedd_set_model(tedd_ctx* ctx, const double consts[17], int32_t model_kind, double eta,
                    const double mms_params[8]);
-/* Execution options.  "blocked_solve" (default 1): solve the Newton systems with the LDS-blocked
- * kernel chain (several Jacobi sweeps per launch) instead of one launch per sweep.
- * "blocked_hmax": sweeps fused per launch (0 = automatic). */
+/* Execution options (no counterpart in the reference; they select between implementations that give
+ * the same results).  "strip_solve" (default 1): solve the Newton systems with the register-resident
+ * kernel chain (several Jacobi sweeps per launch) instead of one launch per sweep; "strip_hmax": sweeps
+ * per launch (0 = automatic, at most 16); "cache_forcing" (default 1): evaluate the closed-form MMS
+ * forcing once per time level into arrays instead of inside the step kernels. */
 int tedd_set_option(tedd_ctx* ctx, const char* name, double value);
 /* Use the caller's HIP stream (hipStream_t passed as void*) for all subsequent work. */
 int tedd_set_stream(tedd_ctx* ctx, void* hip_stream);

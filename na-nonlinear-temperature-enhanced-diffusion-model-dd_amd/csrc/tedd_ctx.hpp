@@ -691,126 +691,31 @@ public:
     }
 
     // options
-    int opt_blocked = 2;      // 0: one launch per sweep; 1: LDS-blocked chain; 2: register-resident chain (backends that have them)
-    int opt_hmax = 0;         // sweeps fused per launch (0 = automatic)
+    int opt_strip = 1;      // 1: register-resident solve chain (backends that have it); 0: one launch per sweep
+    int opt_strip_hmax = 0;         // sweeps fused per launch (0 = automatic)
     bool bT_ready = false;    // slot DA holds rhs/diag of the next T system (written by the predictor launch)
-    int opt_fuse_rhs[3] = {1, 1, 1};  // per system (T, cl, cd): compute the rhs inside the first blocked launch
-
-    template <int VAR, int CASE, int REACT>
-    void newton_solve_blocked(const StepParams& p, const ForcingSrc& f1, const NewtonIn& a, double* unew, int nsweeps,
-                              int slot_id) {
-        if constexpr (Backend::kHasBlockedSolve) {
-            const int fam = (VAR == VAR_T) ? FAM_SOLVE_T : (VAR == VAR_CL) ? FAM_SOLVE_CL : FAM_SOLVE_CD;
-            int remaining = nsweeps - 1;  // delta^1 = rhs/diag comes with the right-hand side
-            int hmax = opt_hmax > 0 ? opt_hmax : ((size_t)nrows * ncols > (size_t)1 << 20 ? 8 : 12);
-            hmax = std::min(hmax, 24);
-            const bool fuse = opt_fuse_rhs[slot_id] != 0;
-            const int L = std::max(1, (remaining + hmax - 1) / hmax);
-            BlockedArgs A;
-            A.g = grid();
-            A.m = model;
-            A.tb = tabs();
-            A.f1 = f1;
-            A.a = a;
-            A.dt = p.dt;
-            A.stats = reinterpret_cast<unsigned long long*>(d_red + 2 * slot_id);
-            A.tiles_x = 0;
-            double* rhs = (L > 1 || !fuse) ? B(RHS) : nullptr;
-            double* dbuf[2] = {(L > 1 || !fuse) ? B(DA) : nullptr, (L > 2 || (!fuse && L > 1)) ? B(DB) : nullptr};
-            const double* din = nullptr;
-            int dsel = 0;
-            if (!fuse) {
-                // right-hand side and delta^1 by the one-thread-per-node kernel (high occupancy)
-                Range r;
-                if (VAR == VAR_T)
-                    r = need({{a.cp1, false}, {a.To, true}, {a.YT, false}});
-                else if (VAR == VAR_CL)
-                    r = need({{a.cp1, true}, {a.To, true}, {a.clo, true}, {a.Tn, true}, {a.Ycl, false}});
-                else
-                    r = need({{a.cp1, true}, {a.To, true}, {a.cdo, true}, {a.clo, false}, {a.cs1, false}, {a.Tn, true},
-                              {a.cln, false}, {a.Ycd, false}});
-                const int fam_rhs = (VAR == VAR_T) ? FAM_RHS_T : (VAR == VAR_CL) ? FAM_RHS_CL : FAM_RHS_CD;
-                NewtonRhsFn<VAR, CASE, REACT> fr{A.g, model, A.tb, f1, a, rhs, dbuf[0], p.dt};
-                be.nodes(fam_rhs, fr, r.lo, r.hi, ncols);
-                mark(rhs, r);
-                mark(dbuf[0], r);
-                din = dbuf[0];
-                dsel = 1;
-            }
-            for (int l = 0; l < L; ++l) {
-                const int ns = (remaining + (L - l) - 1) / (L - l);
-                remaining -= ns;
-                const bool first = (l == 0) && fuse, lastl = (l == L - 1);
-                A.H = ns;
-                A.nsweeps = ns;
-                Range r;
-                if (first) {
-                    if (VAR == VAR_T)
-                        r = need_depth({{a.cp1, false}, {a.To, true}, {a.YT, false}}, ns);
-                    else if (VAR == VAR_CL)
-                        r = need_depth({{a.cp1, true}, {a.To, true}, {a.clo, true}, {a.Tn, true}, {a.Ycl, false}}, ns);
-                    else
-                        r = need_depth({{a.cp1, true}, {a.To, true}, {a.cdo, true}, {a.clo, false}, {a.cs1, false},
-                                        {a.Tn, true}, {a.cln, false}, {a.Ycd, false}}, ns);
-                } else {
-                    if (VAR == VAR_T)
-                        r = need_depth({{a.cp1, false}, {rhs, false}, {din, false}}, ns);
-                    else if (VAR == VAR_CL)
-                        r = need_depth({{a.cp1, true}, {a.To, true}, {rhs, false}, {din, false}}, ns);
-                    else
-                        r = need_depth({{a.cp1, true}, {a.To, true}, {a.clo, false}, {a.cs1, false}, {rhs, false},
-                                        {din, false}}, ns);
-                }
-                A.r0 = r.lo;
-                A.r1 = r.hi;
-                A.rhs_in = first ? nullptr : rhs;
-                A.d_in = din;
-                A.rhs_out = (first && !lastl) ? rhs : nullptr;
-                double* dout = lastl ? nullptr : dbuf[(l + dsel) & 1];
-                A.d_out = dout;
-                A.u_out = lastl ? unew : nullptr;
-                if (first && lastl)
-                    be.template solve_blocked<VAR, CASE, REACT, true, true>(fam, A, ncols);
-                else if (first)
-                    be.template solve_blocked<VAR, CASE, REACT, true, false>(fam, A, ncols);
-                else if (lastl)
-                    be.template solve_blocked<VAR, CASE_STREAM, REACT, false, true>(fam, A, ncols);
-                else
-                    be.template solve_blocked<VAR, CASE_STREAM, REACT, false, false>(fam, A, ncols);
-                if (first && !lastl) mark(rhs, r);
-                if (lastl)
-                    mark(unew, r);
-                else
-                    mark(dout, r);
-                din = dout;
-            }
-        }
-    }
 
     // Register-resident solve chain (tedd_strip.hpp): b = delta^1 = rhs/diag from the node kernel,
     // then ceil((nsweeps-1)/hmax) launches that iterate on (b, delta).
     template <int VAR, int CASE, int REACT>
     void newton_solve_strip(const StepParams& p, const ForcingSrc& f1, const NewtonIn& a, double* unew, int nsweeps,
                             int slot_id) {
-        if constexpr (Backend::kHasBlockedSolve) {
+        if constexpr (Backend::kHasStripSolve) {
             const int fam = (VAR == VAR_T) ? FAM_SOLVE_T : (VAR == VAR_CL) ? FAM_SOLVE_CL : FAM_SOLVE_CD;
             const int fam_rhs = (VAR == VAR_T) ? FAM_RHS_T : (VAR == VAR_CL) ? FAM_RHS_CL : FAM_RHS_CD;
             int remaining = nsweeps - 1;
             // up to 10 sweeps per launch: measured best at 16384^2 (two launches of 10 + 9 for the T
             // system beat three of 7 + 6 + 6 although the column halo is then no longer line-aligned)
-            int hmax = opt_hmax > 0 ? opt_hmax : 10;
+            int hmax = opt_strip_hmax > 0 ? opt_strip_hmax : 10;
             hmax = std::min(hmax, 16);
             const int L = std::max(1, (remaining + hmax - 1) / hmax);
-            BlockedArgs A;
+            StripArgs A;
             A.g = grid();
             A.m = model;
-            A.tb = tabs();
-            A.f1 = f1;
             A.a = a;
             A.dt = p.dt;
             A.stats = reinterpret_cast<unsigned long long*>(d_red + 2 * slot_id);
             A.tiles_x = 0;
-            A.rhs_out = nullptr;
             double* bsc = B(DA);
             double* iter[2] = {B(DB), B(RHS)};
             Range r;
@@ -824,7 +729,7 @@ public:
             if (VAR == VAR_T && bT_ready) {
                 bT_ready = false;  // b came with the predictor launch
             } else {
-                NewtonRhsFn<VAR, CASE, REACT> fr{A.g, model, A.tb, f1, a, nullptr, bsc, p.dt};
+                NewtonRhsFn<VAR, CASE, REACT> fr{A.g, model, tabs(), f1, a, nullptr, bsc, p.dt};
                 be.nodes(fam_rhs, fr, r.lo, r.hi, ncols);
                 mark(bsc, r);
             }
@@ -844,7 +749,7 @@ public:
                                     {din, false}}, ns);
                 A.r0 = r.lo;
                 A.r1 = r.hi;
-                A.rhs_in = bsc;
+                A.b_in = bsc;
                 A.d_in = din;
                 double* dout = lastl ? nullptr : iter[l & 1];
                 A.d_out = dout;
@@ -863,13 +768,9 @@ public:
 
     template <int VAR, int CASE, int REACT>
     void newton_solve(const StepParams& p, const ForcingSrc& f1, const NewtonIn& a, double* unew, int nsweeps, int slot_id) {
-        if constexpr (Backend::kHasBlockedSolve) {
-            if (opt_blocked == 2) {
+        if constexpr (Backend::kHasStripSolve) {
+            if (opt_strip) {
                 newton_solve_strip<VAR, CASE, REACT>(p, f1, a, unew, nsweeps, slot_id);
-                return;
-            }
-            if (opt_blocked) {
-                newton_solve_blocked<VAR, CASE, REACT>(p, f1, a, unew, nsweeps, slot_id);
                 return;
             }
         }
@@ -958,7 +859,7 @@ public:
             // the register-resident solve iterates on b = rhs/diag; for the first T system the predictor
             // kernel has everything b needs
             double* bT = nullptr;
-            if (Backend::kHasBlockedSolve && opt_blocked == 2 && p.num_pc > 0 && p.num_newton > 0) bT = B(DA);
+            if (Backend::kHasStripSolve && opt_strip && p.num_pc > 0 && p.num_newton > 0) bT = B(DA);
             PredictFn<CASE, REACT> f{g, model, tb, f0, f1, fields(cur), YT, Ycl, Ycd, cpP, csP, fcp_t0, fcp_t0_out,
                                      fcp_t1_out, dt, bT, ncp, ycs};
             be.nodes(FAM_PREDICT, f, r.lo, r.hi, ncols);
@@ -1075,18 +976,12 @@ public:
     }
 
     void set_option(const std::string& name, double value) {
-        if (name == "blocked_solve")
-            opt_blocked = (int)value;
-        else if (name == "blocked_hmax")
-            opt_hmax = (int)value;
+        if (name == "strip_solve")
+            opt_strip = value != 0.0;
+        else if (name == "strip_hmax")
+            opt_strip_hmax = (int)value;
         else if (name == "cache_forcing")
             opt_cache_forcing = value != 0.0;
-        else if (name == "fuse_rhs_T")
-            opt_fuse_rhs[0] = value != 0.0;
-        else if (name == "fuse_rhs_cl")
-            opt_fuse_rhs[1] = value != 0.0;
-        else if (name == "fuse_rhs_cd")
-            opt_fuse_rhs[2] = value != 0.0;
         else
             throw InvalidError("unknown option: " + name);
     }

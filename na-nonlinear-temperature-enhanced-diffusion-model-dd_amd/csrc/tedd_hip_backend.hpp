@@ -10,7 +10,6 @@
 #include <string>
 #include <vector>
 
-#include "tedd_blocked.hpp"
 #include "tedd_strip.hpp"
 #include "tedd_ctx.hpp"
 
@@ -254,7 +253,7 @@ struct CorrectClosedFn {
 };
 
 struct HipBackend {
-    static constexpr bool kHasBlockedSolve = true;
+    static constexpr bool kHasStripSolve = true;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int device = -1;
@@ -423,26 +422,12 @@ struct HipBackend {
         hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64), 0, stream, d_partials, nb, (int)F::NR, dev_out);
         TEDD_HIP(hipGetLastError());
     }
-    // one launch of the LDS-blocked Newton solve chain (tedd_blocked.hpp)
-    template <int VAR, int CASE, int REACT, bool FIRST, bool LAST>
-    void solve_blocked(int fam, BlockedArgs A, int ncols) {
-        if (A.r1 <= A.r0) return;
-        if (A.H < 0 || A.H > 24 || A.nsweeps < 0 || A.nsweeps > A.H) throw std::runtime_error("bad blocked-solve depth");
-        Scope sc(this, fam);
-        const int TI = kBT - 2 * A.H;
-        A.tiles_x = (ncols + TI - 1) / TI;
-        const long long nt = (long long)A.tiles_x * ((A.r1 - A.r0 + TI - 1) / TI);
-        if (nt > 0x7fffffffLL) throw std::runtime_error("mesh too large for the tile index");
-        hipLaunchKernelGGL((k_solve_blocked<VAR, CASE, REACT, FIRST, LAST>), dim3((unsigned)nt), dim3(kTileX, kTileY), 0,
-                           stream, A);
-        TEDD_HIP(hipGetLastError());
-    }
     // one launch of the register-resident Newton solve chain (tedd_strip.hpp)
     template <int VAR, int REACT, bool LAST>
-    void solve_strip(int fam, BlockedArgs A, int ncols) {
+    void solve_strip(int fam, StripArgs A, int ncols) {
         if (A.r1 <= A.r0) return;
         if (A.H < 0 || A.H > 16 || A.nsweeps < 0 || A.nsweeps > A.H) throw std::runtime_error("bad strip-solve depth");
-        if (A.rhs_in == nullptr || A.d_in == nullptr) throw std::runtime_error("strip solve needs rhs and delta^1");
+        if (A.b_in == nullptr || A.d_in == nullptr) throw std::runtime_error("strip solve needs rhs and delta^1");
         Scope sc(this, fam);
         const int TIR = kSTile - 2 * A.H, TIC = kSTile - 2 * strip_col_halo(A.H);
         A.tiles_x = (ncols + TIC - 1) / TIC;

@@ -350,18 +350,15 @@ struct NewtonRhsFn {
     }
 };
 
-// Arguments of one launch of the LDS-blocked Newton solve chain (kernel in tedd_blocked.hpp).
-struct BlockedArgs {
+// Arguments of one launch of the register-resident Newton solve chain (kernel in tedd_strip.hpp).
+struct StripArgs {
     GridDev g;
     ModelC m;
-    MmsTabs tb;
-    ForcingSrc f1;
     NewtonIn a;
-    const double* rhs_in;
-    const double* d_in;
-    double* rhs_out;
-    double* d_out;
-    double* u_out;
+    const double* b_in;   // rhs/diag = delta^1
+    const double* d_in;   // current iterate (== b_in for the first launch of a chain)
+    double* d_out;        // next iterate (all launches but the last)
+    double* u_out;        // new unknown (last launch)
     double dt;
     int r0, r1;      // output rows (local)
     int H;           // halo depth of this launch

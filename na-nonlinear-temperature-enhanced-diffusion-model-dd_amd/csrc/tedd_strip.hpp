@@ -76,7 +76,7 @@ __device__ __forceinline__ double lane_above(double v) {
 }
 template <int VAR, int REACT, bool LAST>
 __global__ void __launch_bounds__(64 * StripShape<VAR>::W) __attribute__((amdgpu_waves_per_eu(LAST ? StripShape<VAR>::OCC_LAST : StripShape<VAR>::OCC)))
-k_solve_strip(const BlockedArgs A) {
+k_solve_strip(const StripArgs A) {
     constexpr int R = StripShape<VAR>::R, W = StripShape<VAR>::W;
     constexpr bool LEAN = (VAR == VAR_T);
     __shared__ double seam[2][W][2][kSTile];  // [parity][wave][first/last row of the strip][lane]
@@ -100,8 +100,8 @@ k_solve_strip(const BlockedArgs A) {
     const bool col_interior = (j >= 1 && j <= g.M - 1);
     const int rmax = g.nrows - 1;
 
-    // ---- loads: clamped coordinates, no branches.  rhs_in holds b = rhs/diag = delta^1; the first
-    // launch of a chain starts from it (d_in == rhs_in)
+    // ---- loads: clamped coordinates, no branches.  b_in holds b = rhs/diag = delta^1; the first
+    // launch of a chain starts from it (d_in == b_in)
     double d[R], b[R];
     double cpv[R + 2];  // cp at rows row0-1 .. row0+R
     double Tv[R + 2];   // lagged T at the same rows (cl, cd systems)
@@ -109,7 +109,7 @@ k_solve_strip(const BlockedArgs A) {
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const size_t c = (size_t)min(max(row0 + k, 0), rmax) * g.ld + jc;
-        b[k] = A.rhs_in[c];
+        b[k] = A.b_in[c];
         if (LEAN) d[k] = A.d_in[c];  // (the same line as b[k] in the first launch of a chain)
         if (VAR == VAR_CD) {
             clv[k] = A.a.clo[c];
@@ -213,7 +213,7 @@ k_solve_strip(const BlockedArgs A) {
     // full rows: the iterate is loaded last, until here the registers hold the inputs of the rows.
     // (The empty asm ties the load addresses to the end of the set-up so that the loads are not hoisted.)
     if (LEAN) {
-    } else if (A.d_in == A.rhs_in) {
+    } else if (A.d_in == A.b_in) {
 #pragma unroll
         for (int k = 0; k < R; ++k) d[k] = b[k];
     } else {

@@ -13,7 +13,7 @@
 namespace tedd {
 
 struct CpuBackend {
-    static constexpr bool kHasBlockedSolve = false;
+    static constexpr bool kHasStripSolve = false;
     double fam_ms[FAM_COUNT] = {0};
     long long fam_n[FAM_COUNT] = {0};
     void init(int) {}

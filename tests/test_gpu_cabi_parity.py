@@ -34,17 +34,13 @@ def test_mms_exact_and_forcing(tag):
     assert e_forcing < 1e-13   # relative to the O(1) exact fields the forcing is a residual of
 
 
-# solver variants: one launch per Jacobi sweep; the LDS-blocked chain with its automatic depth and
-# forced to 2 and 3 sweeps per launch (first / middle / last launches all exercised); the
-# register-resident chain (the default) likewise; forcing evaluated in the step kernels instead of
-# once per time level; right-hand side fused into / split from the first LDS-blocked launch
-SOLVERS = {"sweeps": {"blocked_solve": 0}, "blocked": {"blocked_solve": 1},
-           "blocked_h2": {"blocked_solve": 1, "blocked_hmax": 2}, "blocked_h3": {"blocked_solve": 1, "blocked_hmax": 3},
-           "strip": {"blocked_solve": 2}, "strip_h2": {"blocked_solve": 2, "blocked_hmax": 2},
-           "strip_h3": {"blocked_solve": 2, "blocked_hmax": 3}, "strip_h1": {"blocked_solve": 2, "blocked_hmax": 1},
-           "forcing_in_kernels": {"cache_forcing": 0},
-           "blocked_fused_rhs": {"blocked_solve": 1, "cache_forcing": 0, "fuse_rhs_T": 1, "fuse_rhs_cl": 1, "fuse_rhs_cd": 1},
-           "blocked_split_rhs": {"blocked_solve": 1, "fuse_rhs_T": 0, "fuse_rhs_cl": 0, "fuse_rhs_cd": 0}}
+# solver variants: the register-resident solve chain (the default) with its automatic depth and
+# forced to 1, 2 and 3 sweeps per launch (first / middle / last launches all exercised); one launch
+# per Jacobi sweep; forcing evaluated in the step kernels instead of once per time level
+SOLVERS = {"strip": {"strip_solve": 1}, "strip_h1": {"strip_solve": 1, "strip_hmax": 1},
+           "strip_h2": {"strip_solve": 1, "strip_hmax": 2}, "strip_h3": {"strip_solve": 1, "strip_hmax": 3},
+           "sweeps": {"strip_solve": 0}, "forcing_in_kernels": {"cache_forcing": 0},
+           "sweeps_forcing_in_kernels": {"strip_solve": 0, "cache_forcing": 0}}
 
 
 @pytest.mark.parametrize("solver", list(SOLVERS))
