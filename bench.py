@@ -36,7 +36,7 @@ NB_A = dict(R0=8.3144621, Ea=1.60217662e-19, K1=1e-3, K2=1e-3, K3=1e-3, K4=1e-3,
 
 # Distinct full-grid arrays read + written per launch of each kernel family (algorithmic traffic:
 # 8 bytes per node per array; stencil neighbours, tile halos and 1-D tables not counted).
-def arrays_per_launch(solver, cache_forcing, sweeps, hmax):
+def arrays_per_launch(solver, cache_forcing, sweeps, hmax, fuse_forcing=1):
     """-> ({family: arrays per launch (chain families: average over the chain's launches)},
            {chain family: {"launches_per_solve", "arrays_per_solve"}})"""
     a = {}
@@ -44,12 +44,18 @@ def arrays_per_launch(solver, cache_forcing, sweeps, hmax):
         a["forcing"] = 5        # writes fcp (cell averages), fT, fcl, fcd, fcs of the new time level
         a["predict"] = 19       # reads cp,T,cl,cd,cs, the 5 forcing arrays at t0, fcp and fcs at t1; writes Y_T,Y_cl,Y_cd,cp*,cs*, and the t0 parts of the correctors (2)
         f = 1                   # the forcing array each rhs kernel reads
+        if fuse_forcing:
+            # the predictor evaluates the t1 forcing itself: no forcing launch, it reads the 5 arrays
+            # of t0 only and writes the 5 of t1
+            del a["forcing"]
+            a["predict"] += 5 - 2
     else:
         a["predict"] = 14       # reads cp,T,cl,cd,cs + cached fcp(t0); writes Y_T,Y_cl,Y_cd,cp*,cs*,fcp(t1), corrector parts (2)
         f = 0
     a["cs_newton"] = 8          # reads the 2 corrector parts, cs, T_new, cl_new, cd_new; writes cp_new, cs_new
     if solver == "strip":
-        a["predict"] += 1 + f   # + reads fT(t1), writes b = rhs/diag of the T system (no rhs_T launch)
+        # + writes b = rhs/diag of the T system (no rhs_T launch), reading fT(t1) unless it is evaluated here
+        a["predict"] += 1 + (f if not (cache_forcing and fuse_forcing) else 0)
     w = 1 if solver == "strip" else 2           # strip: writes b = rhs/diag; others: rhs and delta_1
     a["rhs_T"] = 3 + f + w      # reads cp*, T, Y_T
     a["rhs_cl"] = 5 + f + w     # reads cp*, T, T_new, cl, Y_cl
@@ -170,6 +176,8 @@ def main():
     ap.add_argument("--hmax", type=int, default=10, help="Jacobi sweeps fused per launch of a solve chain")
     ap.add_argument("--cache-forcing", type=int, default=1,
                     help="1: forcing arrays evaluated once per time level; 0: inside the step kernels")
+    ap.add_argument("--fuse-forcing", type=int, default=1,
+                    help="with --cache-forcing 1: the predictor launch evaluates the forcing arrays of t1 itself")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (repeatable)")
     args = ap.parse_args()
 
@@ -201,6 +209,7 @@ def main():
     stepper = SlabStepper(ctx, slab, device)
     ctx.set_option("strip_solve", 1 if args.solver == "strip" else 0)
     ctx.set_option("cache_forcing", args.cache_forcing)
+    ctx.set_option("fuse_forcing", args.fuse_forcing)
     ctx.set_option("strip_hmax", args.hmax)
     for kv in args.opt:
         name, value = kv.split("=")
@@ -243,7 +252,7 @@ def main():
     err_H = float(np.sqrt(np.sum(norms[:5])))
 
     n_nodes_local = (slab.row_hi - slab.row_lo) * (N + 1)
-    arrays, chains = arrays_per_launch(args.solver, args.cache_forcing, sweeps, args.hmax)
+    arrays, chains = arrays_per_launch(args.solver, args.cache_forcing, sweeps, args.hmax, args.fuse_forcing)
 
     def gbps(fam):
         per_launch_s = prof[fam]["total_ms"] / prof[fam]["launches"] * 1e-3
@@ -263,8 +272,9 @@ def main():
     arrays_step = sum(arrays.get(k, 0) * v["launches"] for k, v in prof.items()) / args.steps
     step_gbs = 8.0 * (N + 1) * (N + 1) * arrays_step * args.steps / elapsed / 1e9
 
-    cfg_key = {"mesh_N": N, "solver": args.solver, "sweeps_per_launch": args.hmax,
-               "forcing": "arrays per time level" if args.cache_forcing else "closed form inside the step kernels"}
+    forcing_mode = ("closed form inside the step kernels" if not args.cache_forcing else
+                    "arrays per time level, made by the predictor launch" if args.fuse_forcing else "arrays per time level")
+    cfg_key = {"mesh_N": N, "solver": args.solver, "sweeps_per_launch": args.hmax, "forcing": forcing_mode}
     if roofline is not None:
         tr = pmc_traffic(fam, cfg_key)
         if tr is not None:
@@ -280,7 +290,7 @@ def main():
                                f"eta=50, notebook model constants, 1 PC x 1 Newton step, 5 cs-Newton iterations",
                    "mesh_N": N, "jacobi_sweeps": sweeps, "jacobi_tol": args.jacobi_tol,
                    "solver": args.solver, "sweeps_per_launch": args.hmax, "solve_chains": chains,
-                   "forcing": "arrays per time level" if args.cache_forcing else "closed form inside the step kernels",
+                   "forcing": forcing_mode,
                    "parallelism": f"row slabs x{world}, ghost={slab.ghost}", "error_H_after_run": err_H},
         "roofline": roofline,
         "step_hbm": {"algorithmic_arrays_per_step": arrays_step, "achieved_GBps_all_gpus": step_gbs,

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <stdexcept>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -98,6 +99,8 @@ public:
     // forcing cache (closed-form cases): the five forcing arrays of a time level are evaluated
     // once by ForcingFn and the step kernels read them like streamed forcing
     int opt_cache_forcing = 1;
+    int opt_fuse_forcing = 1;        // with the cache: the predictor launch evaluates the t1 set itself
+    bool predict_makes_f1 = false;
     int fset[2] = {0, 1};            // which physical array set serves time level 0 / 1
     double fset_time[2] = {NAN, NAN};
     bool forcing_from_cache = false;
@@ -653,7 +656,13 @@ public:
                 fill_forcing_set(t0, k0);
             }
             const int k1 = 1 - k0;
-            fill_forcing_set(t0 + dt, k1);
+            if (opt_fuse_forcing) {
+                predict_makes_f1 = true;  // the predictor launch evaluates the t1 set (step_pc_impl)
+                for (int v = 0; v < 5; ++v) B((k1 ? SF10 : SF00) + v);
+                fset_time[k1] = t0 + dt;
+            } else {
+                fill_forcing_set(t0 + dt, k1);
+            }
             fset[0] = k0;
             fset[1] = k1;
             forcing_from_cache = true;
@@ -860,9 +869,37 @@ public:
             // kernel has everything b needs
             double* bT = nullptr;
             if (Backend::kHasStripSolve && opt_strip && p.num_pc > 0 && p.num_newton > 0) bT = B(DA);
-            PredictFn<CASE, REACT> f{g, model, tb, f0, f1, fields(cur), YT, Ycl, Ycd, cpP, csP, fcp_t0, fcp_t0_out,
-                                     fcp_t1_out, dt, bT, ncp, ycs};
-            be.nodes(FAM_PREDICT, f, r.lo, r.hi, ncols);
+            bool launched = false;
+            if constexpr (CASE == CASE_STREAM) {
+                if (predict_makes_f1) {
+                    // array-fed forcing whose t1 set is still to be made: this launch makes it
+                    predict_makes_f1 = false;
+                    Out5 fo;
+                    for (int v = 0; v < 5; ++v) fo.v[v] = const_cast<double*>(f1.f[v]);
+                    ForcingSrc f1c = f1;
+                    f1c.tm = mms_time_fill(mms_case, model, mp, t1);
+                    auto launch = [&](auto fcase) {
+                        PredictFn<CASE_STREAM, REACT, decltype(fcase)::value> f{
+                            g, model, tb, f0, f1c, fields(cur), YT, Ycl, Ycd, cpP, csP, fcp_t0, fcp_t0_out,
+                            fcp_t1_out, dt, bT, ncp, ycs, fo};
+                        be.nodes(FAM_PREDICT, f, r.lo, r.hi, ncols);
+                    };
+                    switch (mms_case) {
+                        case CASE_POL: launch(std::integral_constant<int, CASE_POL>{}); break;
+                        case CASE_EXPSIN: launch(std::integral_constant<int, CASE_EXPSIN>{}); break;
+                        case CASE_PEAKS: launch(std::integral_constant<int, CASE_PEAKS>{}); break;
+                        case CASE_NFS: launch(std::integral_constant<int, CASE_NFS>{}); break;
+                        default: throw InvalidError("no closed-form case to evaluate the forcing from");
+                    }
+                    for (int v = 0; v < 5; ++v) mark(fo.v[v], r);
+                    launched = true;
+                }
+            }
+            if (!launched) {
+                PredictFn<CASE, REACT> f{g, model, tb, f0, f1, fields(cur), YT, Ycl, Ycd, cpP, csP, fcp_t0, fcp_t0_out,
+                                         fcp_t1_out, dt, bT, ncp, ycs, Out5{}};
+                be.nodes(FAM_PREDICT, f, r.lo, r.hi, ncols);
+            }
             for (double* q : {YT, Ycl, Ycd, cpP, csP, ncp, ycs}) mark(q, r);
             if (bT) mark(bT, r);
             bT_ready = (bT != nullptr);
@@ -982,6 +1019,8 @@ public:
             opt_strip_hmax = (int)value;
         else if (name == "cache_forcing")
             opt_cache_forcing = value != 0.0;
+        else if (name == "fuse_forcing")
+            opt_fuse_forcing = value != 0.0;
         else
             throw InvalidError("unknown option: " + name);
     }

@@ -139,7 +139,11 @@ struct FieldFn {
 // K_pred: Y_v = dt F_v(S0,t0) + 2 v0 for v in {T,cl,cd}; Heun predictors for cp and cs.
 // fcp_t0 (optional): cell-averaged cp-forcing at t0 computed by the previous step;
 // fcp_t1 (optional): where to keep the one at t1 for the next step.
-template <int CASE, int REACT>
+// FCASE (array-fed forcing only, CASE == CASE_STREAM): closed-form case whose forcing at t1 this
+// launch evaluates itself and stores into the t1 arrays f1_out for the kernels that follow and for
+// the next step (whose t0 it is) -- the arithmetic of the forcing hides under the memory traffic
+// of the predictor instead of taking a launch of its own.
+template <int CASE, int REACT, int FCASE = CASE_STREAM>
 struct PredictFn {
     GridDev g;
     ModelC m;
@@ -160,6 +164,7 @@ struct PredictFn {
     //     = 2 cs0 + dt Fcs(S0,t0) + dt fcs1         (HCsTriple, prob1base.py:3376-3430)
     //     = (1 + dt/2 b0) cs0 + dt/2 (fcs0 + fcs1)    (CsTriple, prob1base.py:3190-3219)
     double *ncp, *ycs;
+    Out5 f1_out;  // FCASE only
     TEDD_HD void operator()(int li, int j) const {
         const bool in = is_interior(g, li, j);
         const size_t c = at(g, li, j);
@@ -174,7 +179,17 @@ struct PredictFn {
         Ycd[c] = dt * F.cd + 2.0 * cd0;
         // forcing at t1: only fcp (cell average) and fcs are needed here
         double fcp1, fcs1, fT1 = 0.0;
-        if (CASE == CASE_STREAM) {
+        if (CASE == CASE_STREAM && FCASE != CASE_STREAM) {
+            const Forcing5 fb = node_forcing<FCASE, REACT>(m, tb, f1, g, li, j, in, true);
+            fcp1 = fb.fcp;
+            fcs1 = fb.fcs;
+            fT1 = fb.fT;
+            f1_out.v[0][c] = fb.fcp;
+            f1_out.v[1][c] = fb.fT;
+            f1_out.v[2][c] = fb.fcl;
+            f1_out.v[3][c] = fb.fcd;
+            f1_out.v[4][c] = fb.fcs;
+        } else if (CASE == CASE_STREAM) {
             fcp1 = f1.f[0][c];
             fcs1 = f1.f[4][c];
             if (bT) fT1 = f1.f[1][c];

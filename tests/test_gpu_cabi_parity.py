@@ -36,10 +36,12 @@ def test_mms_exact_and_forcing(tag):
 
 # solver variants: the register-resident solve chain (the default) with its automatic depth and
 # forced to 1, 2 and 3 sweeps per launch (first / middle / last launches all exercised); one launch
-# per Jacobi sweep; forcing evaluated in the step kernels instead of once per time level
+# per Jacobi sweep; forcing evaluated in the step kernels instead of once per time level; forcing
+# arrays made by a launch of their own instead of by the predictor launch
 SOLVERS = {"strip": {"strip_solve": 1}, "strip_h1": {"strip_solve": 1, "strip_hmax": 1},
            "strip_h2": {"strip_solve": 1, "strip_hmax": 2}, "strip_h3": {"strip_solve": 1, "strip_hmax": 3},
            "sweeps": {"strip_solve": 0}, "forcing_in_kernels": {"cache_forcing": 0},
+           "forcing_launch": {"fuse_forcing": 0},
            "sweeps_forcing_in_kernels": {"strip_solve": 0, "cache_forcing": 0}}
 
 

@@ -53,10 +53,11 @@ def test_integrator_steps(tag):
 
 
 @pytest.mark.parametrize("tag", cc.tags("golden_steps.npz", "/t0"))
-def test_integrator_steps_with_forcing_evaluated_inside_the_step_kernels(tag):
+@pytest.mark.parametrize("options", [{"cache_forcing": 0}, {"fuse_forcing": 0}], ids=["in_kernels", "own_launch"])
+def test_integrator_steps_with_other_forcing_modes(tag, options):
     if not tag.startswith("pc"):
-        pytest.skip("the forcing cache serves the predictor-corrector step")
-    err, res_err, stats = cc.run_steps(tag, options={"cache_forcing": 0})
+        pytest.skip("the forcing modes concern the predictor-corrector step")
+    err, res_err, stats = cc.run_steps(tag, options=options)
     assert err < (2e-12 if "bigdt" in tag else 5e-14), (tag, err, stats)
     assert res_err < 1e-13, (tag, res_err)
 

@@ -1,6 +1,7 @@
 """Per-kernel means of rocprofv3 --pmc passes (counter_collection CSVs) -> JSON for profiles/.
 
-usage: pmc_summary.py out.json mesh_N solver sweeps_per_launch cache_forcing pass1.csv [pass2.csv ...]
+usage: pmc_summary.py out.json mesh_N solver sweeps_per_launch forcing_mode pass1.csv [pass2.csv ...]
+(forcing_mode: the string bench.py prints in config.forcing)
 The second launch of the cs-Newton kernel in a step returns at once (no early exit): its near-zero
 samples are dropped."""
 import collections
@@ -8,7 +9,7 @@ import csv
 import json
 import sys
 
-out, mesh, solver, hmax, cache = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+out, mesh, solver, hmax, forcing = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for fn in sys.argv[6:]:
     for r in csv.DictReader(open(fn)):
@@ -21,6 +22,6 @@ for k, v in agg.items():
         xs = [y for y in x if y > 0.05 * max(x)] if ("cs_newton" in k and max(x) > 0) else x
         kernels[k][c] = {"mean": sum(xs) / len(xs), "n": len(xs)}
 json.dump({"config": {"mesh_N": mesh, "solver": solver, "sweeps_per_launch": hmax,
-                      "forcing": "arrays per time level" if cache else "closed form inside the step kernels"},
+                      "forcing": forcing},
            "units": {"FETCH_SIZE": "KB (x2 on gfx950 for coalesced streaming reads)", "WRITE_SIZE": "KB"},
            "kernels": kernels}, open(out, "w"), indent=1)
