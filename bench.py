@@ -176,8 +176,9 @@ def main():
     ap.add_argument("--hmax", type=int, default=10, help="Jacobi sweeps fused per launch of a solve chain")
     ap.add_argument("--cache-forcing", type=int, default=1,
                     help="1: forcing arrays evaluated once per time level; 0: inside the step kernels")
-    ap.add_argument("--fuse-forcing", type=int, default=1,
-                    help="with --cache-forcing 1: the predictor launch evaluates the forcing arrays of t1 itself")
+    ap.add_argument("--fuse-forcing", type=int, default=-1,
+                    help="with --cache-forcing 1: the predictor launch evaluates the forcing arrays of t1 itself "
+                         "(-1: the library's rule, slabs of at most 4 M nodes)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (repeatable)")
     args = ap.parse_args()
 
@@ -210,6 +211,8 @@ def main():
     ctx.set_option("strip_solve", 1 if args.solver == "strip" else 0)
     ctx.set_option("cache_forcing", args.cache_forcing)
     ctx.set_option("fuse_forcing", args.fuse_forcing)
+    if args.fuse_forcing < 0:
+        args.fuse_forcing = int(ctx.nrows * (N + 1) <= (1 << 22))
     ctx.set_option("strip_hmax", args.hmax)
     for kv in args.opt:
         name, value = kv.split("=")

@@ -83,7 +83,8 @@ int tedd_set_model(tedd_ctx* ctx, const double consts[17], int32_t model_kind, d
  * the same results).  "strip_solve" (default 1): solve the Newton systems with the register-resident
  * kernel chain (several Jacobi sweeps per launch) instead of one launch per sweep; "strip_hmax": sweeps
  * per launch (0 = automatic, at most 16); "cache_forcing" (default 1): evaluate the closed-form MMS
- * forcing once per time level into arrays instead of inside the step kernels. */
+ * forcing once per time level into arrays instead of inside the step kernels; "fuse_forcing" (default -1:
+ * slabs of at most 4 M nodes): those arrays are made by the predictor launch instead of a launch of their own. */
 int tedd_set_option(tedd_ctx* ctx, const char* name, double value);
 /* Use the caller's HIP stream (hipStream_t passed as void*) for all subsequent work. */
 int tedd_set_stream(tedd_ctx* ctx, void* hip_stream);

@@ -99,7 +99,13 @@ public:
     // forcing cache (closed-form cases): the five forcing arrays of a time level are evaluated
     // once by ForcingFn and the step kernels read them like streamed forcing
     int opt_cache_forcing = 1;
-    int opt_fuse_forcing = 1;        // with the cache: the predictor launch evaluates the t1 set itself
+    // with the cache: the predictor launch evaluates the t1 set itself (one launch fewer: +2..4 % on
+    // launch-bound meshes) or a launch of its own does (same time on big meshes, and the predictor
+    // then runs closer to the HBM roofline).  -1: fuse up to 4 M nodes per slab.
+    int opt_fuse_forcing = -1;
+    bool fuse_forcing_now() const {
+        return opt_fuse_forcing < 0 ? (size_t)nrows * ncols <= ((size_t)1 << 22) : opt_fuse_forcing != 0;
+    }
     bool predict_makes_f1 = false;
     int fset[2] = {0, 1};            // which physical array set serves time level 0 / 1
     double fset_time[2] = {NAN, NAN};
@@ -656,7 +662,7 @@ public:
                 fill_forcing_set(t0, k0);
             }
             const int k1 = 1 - k0;
-            if (opt_fuse_forcing) {
+            if (fuse_forcing_now()) {
                 predict_makes_f1 = true;  // the predictor launch evaluates the t1 set (step_pc_impl)
                 for (int v = 0; v < 5; ++v) B((k1 ? SF10 : SF00) + v);
                 fset_time[k1] = t0 + dt;
@@ -1020,7 +1026,7 @@ public:
         else if (name == "cache_forcing")
             opt_cache_forcing = value != 0.0;
         else if (name == "fuse_forcing")
-            opt_fuse_forcing = value != 0.0;
+            opt_fuse_forcing = value < 0.0 ? -1 : (value != 0.0);
         else
             throw InvalidError("unknown option: " + name);
     }
