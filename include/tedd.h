@@ -130,6 +130,23 @@ int tedd_advance(tedd_ctx* ctx, double t0, double dt, int32_t nsteps, int32_t in
                  int32_t num_newton_steps, int32_t cs_newton_iterations, double cs_consec_xs_rtol,
                  const int32_t jacobi_sweeps[3], double jacobi_tol, int32_t jacobi_max, double* err_series);
 
+/* The pieces of a predictor-corrector step, as the reference exposes them on the integrator.  The state
+ * set by tedd_set_state is their `at_t` / `at_t0`; all arrays are host arrays of the local mesh shape.
+ *
+ * tedd_predict_cp_cs: initial_cp_pred (src/prob1base.py:2953-2965) and initial_cs_pred (:3174-3188
+ * CsTriple, :3354-3374 HCsTriple, :3631-3645 RegHCsTriple); either output may be NULL.
+ * tedd_correct_cp_cs: corrector_cp_step (:2967-2996) and corrector_cs_step (:3190-3219, :3376-3430,
+ * :3665-3702) given the new T, cl, cd; either output may be NULL.
+ * tedd_newton_step: newton_step_T / _cl / _cd (:2998-3045, :3047-3080, :3082-3115) for var = 1 / 2 / 3 with
+ * the state as the lagged state: Y = dt F_v(S0,t0) + 2 v0 from the caller, T1 (var 2, 3) and cl1 (var 3) the
+ * already updated unknowns; out = the updated unknown, residual (may be NULL) = last_residual[v]. */
+int tedd_predict_cp_cs(tedd_ctx* ctx, double t, double dt, double* cp1, double* cs1);
+int tedd_correct_cp_cs(tedd_ctx* ctx, double t0, double dt, const double* T1, const double* cl1, const double* cd1,
+                       int32_t cs_newton_iterations, double cs_consec_xs_rtol, double* cp1, double* cs1);
+int tedd_newton_step(tedd_ctx* ctx, int32_t var, double t0, double dt, const double* Y, const double* T1,
+                     const double* cl1, int32_t jacobi_sweeps, double jacobi_tol, int32_t jacobi_max, double* out,
+                     double* residual);
+
 /* last_residual["T"|"cl"|"cd"] of the last predictor-corrector step (src/prob1base.py:3041-3043,
  * 3076-3078, 3111-3113); computed on demand. */
 int tedd_get_residuals(tedd_ctx* ctx, double* rT, double* rcl, double* rcd);

@@ -154,6 +154,31 @@ int tedd_advance(tedd_ctx* ctx, double t0, double dt, int32_t nsteps, int32_t in
                   jacobi_max, err_series);
     });
 }
+int tedd_predict_cp_cs(tedd_ctx* ctx, double t, double dt, double* cp1, double* cs1) {
+    return guarded(ctx, [&](auto& C) {
+        const double* in[3] = {nullptr, nullptr, nullptr};
+        double* out[2] = {cp1, cs1};
+        C.substep(0, t, dt, in, out, 0, 0.0, 0, 0.0, 0);
+    });
+}
+int tedd_correct_cp_cs(tedd_ctx* ctx, double t0, double dt, const double* T1, const double* cl1, const double* cd1,
+                       int32_t cs_newton_iterations, double cs_consec_xs_rtol, double* cp1, double* cs1) {
+    return guarded(ctx, [&](auto& C) {
+        const double* in[3] = {T1, cl1, cd1};
+        double* out[2] = {cp1, cs1};
+        C.substep(1, t0, dt, in, out, cs_newton_iterations, cs_consec_xs_rtol, 0, 0.0, 0);
+    });
+}
+int tedd_newton_step(tedd_ctx* ctx, int32_t var, double t0, double dt, const double* Y, const double* T1,
+                     const double* cl1, int32_t jacobi_sweeps, double jacobi_tol, int32_t jacobi_max, double* out,
+                     double* residual) {
+    return guarded(ctx, [&](auto& C) {
+        if (var < 1 || var > 3) throw tedd::InvalidError("var must be 1 (T), 2 (cl) or 3 (cd)");
+        const double* in[3] = {Y, T1, cl1};
+        double* o[2] = {out, residual};
+        C.substep(1 + var, t0, dt, in, o, 0, 0.0, jacobi_sweeps, jacobi_tol, jacobi_max);
+    });
+}
 int tedd_get_residuals(tedd_ctx* ctx, double* rT, double* rcl, double* rcd) {
     return guarded(ctx, [&](auto& C) {
         double* h[3] = {rT, rcl, rcd};

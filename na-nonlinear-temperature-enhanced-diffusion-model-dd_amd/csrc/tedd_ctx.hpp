@@ -983,6 +983,140 @@ public:
         stream_forcing_set[0] = stream_forcing_set[1] = false;
     }
 
+    // ------------------------------------------------------------------ sub-steps of the step
+    // The pieces of the predictor-corrector step the reference exposes as methods of the integrator
+    // (src/prob1base.py:2946-3115).  The state set by tedd_set_state is their `at_t` / `at_t0`; further
+    // inputs and the results are host arrays.  They run the same kernels as step_pc.
+    struct SubstepOp {
+        Ctx* c;
+        int what;  // 0 predictors, 1 correctors, 2/3/4 Newton step for T/cl/cd
+        double t0, dt;
+        const double* in[3];
+        double* out[2];
+        int cs_iters;
+        double cs_rtol;
+        int sweeps;
+        double jtol;
+        int jmax;
+        template <int CASE, int REACT>
+        void run() {
+            c->template substep_impl<CASE, REACT>(*this);
+        }
+    };
+    struct Pooled {  // pool buffers handed back on scope exit
+        Ctx* c;
+        std::vector<double*> p;
+        explicit Pooled(Ctx* c_) : c(c_) {}
+        double* get() {
+            p.push_back(c->acquire());
+            return p.back();
+        }
+        double* upload(const double* h) {
+            if (!h) throw InvalidError("missing input array");
+            double* d = get();
+            c->upload_field(d, h);
+            return d;
+        }
+        ~Pooled() {
+            for (double* q : p) c->release(q);
+        }
+    };
+    template <int CASE, int REACT>
+    void substep_impl(const SubstepOp& op) {
+        const GridDev g = grid();
+        const MmsTabs tb = tabs();
+        const double t0 = op.t0, dt = op.dt, t1 = op.t0 + op.dt;
+        Pooled pool(this);
+        int flag = 0;
+        if (op.what <= 1) {
+            // predictors, and the t0 parts of the correctors, from the predictor kernel
+            const ForcingSrc f0 = forcing_src(t0, 0), f1 = forcing_src(t1, 1);
+            double *YT = pool.get(), *Ycl = pool.get(), *Ycd = pool.get(), *cpP = pool.get(), *csP = pool.get(),
+                   *ncp = pool.get(), *ycs = pool.get();
+            Range r = need({{cur[0], true}, {cur[1], true}, {cur[2], true}, {cur[3], true}, {cur[4], false}});
+            PredictFn<CASE, REACT> f{g, model, tb, f0, f1, fields(cur), YT, Ycl, Ycd, cpP, csP, nullptr, nullptr,
+                                     nullptr, dt, nullptr, ncp, ycs, Out5{}};
+            be.nodes(FAM_PREDICT, f, r.lo, r.hi, ncols);
+            for (double* q : {cpP, csP, ncp, ycs}) mark(q, r);
+            if (op.what == 0) {
+                if (op.out[0]) download_field(op.out[0], cpP);
+                if (op.out[1]) download_field(op.out[1], csP);
+            } else {
+                double *T1 = pool.upload(op.in[0]), *cl1 = pool.upload(op.in[1]), *cd1 = pool.upload(op.in[2]);
+                double *cpN = pool.get(), *csN = pool.get();
+                CorrectIn<CASE, REACT> ci{g, model, ncp, ycs, cur[VAR_CS], T1, cl1, cd1, dt};
+                Range rc = need({{ncp, false}, {ycs, false}, {cur[VAR_CS], false}});
+                be.template correct<CASE, REACT>(ci, rc.lo, rc.hi, ncols, cpN, csN, op.cs_iters, op.cs_rtol, d_ints);
+                if (op.out[0]) download_field(op.out[0], cpN);
+                if (op.out[1]) download_field(op.out[1], csN);
+                if (REACT == REACT_HCS) be.d2h(&flag, d_ints + 1, sizeof(int));
+            }
+        } else {
+            // one Newton step of the trapezoidal rule for T, cl or cd with the state as lagged state
+            const int var = op.what - 1;  // VAR_T, VAR_CL, VAR_CD
+            const ForcingSrc f1 = forcing_src(t1, 1);
+            NewtonIn a;
+            a.cp1 = cur[VAR_CP];
+            a.cs1 = cur[VAR_CS];
+            a.To = cur[VAR_T];
+            a.clo = cur[VAR_CL];
+            a.cdo = cur[VAR_CD];
+            double* Y = pool.upload(op.in[0]);
+            a.YT = a.Ycl = a.Ycd = Y;
+            a.Tn = (var != VAR_T) ? pool.upload(op.in[1]) : nullptr;
+            a.cln = (var == VAR_CD) ? pool.upload(op.in[2]) : nullptr;
+            const double dcoef[3] = {model.DT, model.Dl_max, model.Dd_max};
+            const int sw = op.sweeps > 0 ? std::max(2, op.sweeps)
+                                         : auto_sweeps(dt * std::fabs(dcoef[var - 1]) * q_metric, op.jtol, op.jmax);
+            StepParams p{t0, dt, 1, 1, 0, 0.0, {sw, sw, sw}};
+            be.memset0(d_red, 8 * sizeof(double));
+            bT_ready = false;
+            double* unew = pool.get();
+            double* res = op.out[1] ? pool.get() : nullptr;
+            if (res) be.memset0(res, field_elems() * sizeof(double));
+            const double *cp = cur[VAR_CP], *cs = cur[VAR_CS];
+            if (var == VAR_T) {
+                newton_solve<VAR_T, CASE, REACT>(p, f1, a, unew, sw, 0);
+                if (res) {
+                    Range r = need({{cp, false}, {unew, true}, {Y, false}});
+                    ResidualFn<VAR_T, CASE, REACT> f{g, model, tb, f1, cp, cs, unew, a.clo, a.cdo, Y, res, dt};
+                    be.nodes(FAM_RESIDUAL, f, r.lo, r.hi, ncols);
+                }
+            } else if (var == VAR_CL) {
+                newton_solve<VAR_CL, CASE, REACT>(p, f1, a, unew, sw, 1);
+                if (res) {
+                    Range r = need({{cp, true}, {a.Tn, true}, {unew, true}, {Y, false}});
+                    ResidualFn<VAR_CL, CASE, REACT> f{g, model, tb, f1, cp, cs, a.Tn, unew, a.cdo, Y, res, dt};
+                    be.nodes(FAM_RESIDUAL, f, r.lo, r.hi, ncols);
+                }
+            } else {
+                newton_solve<VAR_CD, CASE, REACT>(p, f1, a, unew, sw, 2);
+                if (res) {
+                    Range r = need({{cp, true}, {a.Tn, true}, {unew, true}, {a.cln, false}, {cs, false}, {Y, false}});
+                    ResidualFn<VAR_CD, CASE, REACT> f{g, model, tb, f1, cp, cs, a.Tn, a.cln, unew, Y, res, dt};
+                    be.nodes(FAM_RESIDUAL, f, r.lo, r.hi, ncols);
+                }
+            }
+            for (int v = 0; v < 3; ++v) last.sweeps[v] = sw;
+            if (op.out[0]) download_field(op.out[0], unew);
+            if (res) download_field(op.out[1], res);
+        }
+        be.sync();
+        stream_forcing_set[0] = stream_forcing_set[1] = false;
+        raise_corrector_flag(flag);
+    }
+    void substep(int what, double t0, double dt, const double* const in[3], double* const out[2], int cs_iters,
+                 double cs_rtol, int sweeps, double jtol, int jmax) {
+        require_state();
+        if (!(dt > 0)) throw AssertError("dt must be > 0");
+        if (what < 0 || what > 4) throw InvalidError("unknown sub-step");
+        if (cs_iters < 0 || cs_iters > 4096) throw InvalidError("cs_newton_iterations must be in [0, 4096]");
+        if (!(jtol > 0)) jtol = 1e-13;
+        if (jmax < 2) jmax = 2;
+        SubstepOp op{this, what, t0, dt, {in[0], in[1], in[2]}, {out[0], out[1]}, cs_iters, cs_rtol, sweeps, jtol, jmax};
+        dispatch(op);
+    }
+
     // ------------------------------------------------------------------ residuals of the last step
     struct ResOp {
         Ctx* c;

@@ -67,6 +67,11 @@ PROTOTYPES = {
     "tedd_step_feuler": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "tedd_advance": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32,
                                C.c_int32, C.c_int32, C.c_double, _i32ptr, C.c_double, C.c_int32, _dptr]),
+    "tedd_predict_cp_cs": (C.c_int, [C.c_void_p, C.c_double, C.c_double, _dptr, _dptr]),
+    "tedd_correct_cp_cs": (C.c_int, [C.c_void_p, C.c_double, C.c_double, _dptr, _dptr, _dptr, C.c_int32, C.c_double,
+                                     _dptr, _dptr]),
+    "tedd_newton_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, _dptr, _dptr, _dptr, C.c_int32,
+                                   C.c_double, C.c_int32, _dptr, _dptr]),
     "tedd_get_residuals": (C.c_int, [C.c_void_p] + [_dptr] * 3),
     "tedd_eval_field": (C.c_int, [C.c_void_p, C.c_double] + [_dptr] * 5),
     "tedd_eval_exact": (C.c_int, [C.c_void_p, C.c_double] + [_dptr] * 5),
@@ -256,6 +261,30 @@ class Context:
                                            self._sweeps(jacobi_sweeps), float(jacobi_tol), jacobi_max,
                                            _arr(series)))
         return series
+
+    # -- the pieces of a predictor-corrector step (the set state is at_t / at_t0)
+    def predict_cp_cs(self, t, dt):
+        cp1, cs1 = self._out(2)
+        self._check(self._lib.tedd_predict_cp_cs(self._h, float(t), float(dt), _arr(cp1), _arr(cs1)))
+        return cp1, cs1
+
+    def correct_cp_cs(self, t0, dt, T1, cl1, cd1, *, cs_newton_iterations=5, cs_consec_xs_rtol=1e-6):
+        ins = [self._in(a) for a in (T1, cl1, cd1)]
+        cp1, cs1 = self._out(2)
+        self._check(self._lib.tedd_correct_cp_cs(self._h, float(t0), float(dt), *[_arr(a) for a in ins],
+                                                 int(cs_newton_iterations), float(cs_consec_xs_rtol),
+                                                 _arr(cp1), _arr(cs1)))
+        return cp1, cs1
+
+    def newton_step(self, var, t0, dt, Y, T1=None, cl1=None, *, jacobi_sweeps=0, jacobi_tol=1e-13,
+                    jacobi_max=100000):
+        """var: 1 T, 2 cl, 3 cd.  Returns (updated unknown, residual)."""
+        ins = [self._in(a) if a is not None else None for a in (Y, T1, cl1)]
+        out, res = self._out(2)
+        self._check(self._lib.tedd_newton_step(self._h, int(var), float(t0), float(dt), *[_arr(a) for a in ins],
+                                               int(jacobi_sweeps), float(jacobi_tol), int(jacobi_max),
+                                               _arr(out), _arr(res)))
+        return out, res
 
     def get_residuals(self):
         out = self._out(3)

@@ -947,6 +947,58 @@ class P_ModifiedEuler_C_Trapezoidal_TimeIntegratorBase(ABC):
             field._model = self._model
         return field, field._device()
 
+    # ---- the pieces of step(), callable on their own like the reference's (src/prob1base.py:2946-3115)
+    def _substep_session(self, state, t0, dt):
+        field, s = self._session()
+        s.load_state(state)
+        if s.mms_case == _ffi.MMS_STREAM:
+            field._stream_forcing(s, 0, t0)
+            field._stream_forcing(s, 1, t0 + dt)
+        return s
+
+    def initial_cp_pred(self, at_t, t, *, dt):
+        """Heun predictor for cp with the other fields frozen (reference src/prob1base.py:2953-2965)."""
+        return self._substep_session(at_t, t, dt).ctx.predict_cp_cs(t, dt)[0]
+
+    def initial_cs_pred(self, at_t, t, *, dt):
+        """Heun predictor for cs (reference src/prob1base.py:3174-3188, 3354-3374, 3631-3645)."""
+        return self._substep_session(at_t, t, dt).ctx.predict_cp_cs(t, dt)[1]
+
+    def corrector_cp_step(self, T1, cl1, _cd1_ignored, *, at_t0, t0, dt):
+        """Closed-form trapezoidal corrector for cp (reference src/prob1base.py:2967-2996)."""
+        assert dt > 0
+        s = self._substep_session(at_t0, t0, dt)
+        cd1 = _cd1_ignored if _cd1_ignored is not None else at_t0.cd
+        return s.ctx.correct_cp_cs(t0, dt, T1, cl1, cd1, **self._cs_newton_args())[0]
+
+    def corrector_cs_step(self, _T1_ignored, cl1, cd1, *, at_t0, t0, dt):
+        """Corrector for cs (reference src/prob1base.py:3190-3219, 3376-3430, 3665-3702)."""
+        s = self._substep_session(at_t0, t0, dt)
+        T1 = _T1_ignored if _T1_ignored is not None else at_t0.T
+        return s.ctx.correct_cp_cs(t0, dt, T1, cl1, cd1, **self._cs_newton_args())[1]
+
+    def _newton(self, var, name, at_t0, t0, dt, Y, T1=None, cl1=None):
+        s = self._substep_session(at_t0, t0, dt)
+        sweeps = 0 if self.jacobi_sweeps is None else int(self.jacobi_sweeps[var - 1])
+        out, res = s.ctx.newton_step(var, t0, dt, Y, T1, cl1, jacobi_sweeps=sweeps, jacobi_tol=self.jacobi_tol,
+                                     jacobi_max=self.jacobi_max)
+        if not isinstance(self.last_residual, dict):
+            self.last_residual = {}
+        self.last_residual[name] = res
+        return out
+
+    def newton_step_T(self, at_t0: StateVars, *, t0, dt, YT0):
+        """One Newton step of the trapezoidal rule for T (reference src/prob1base.py:2998-3045)."""
+        return self._newton(1, "T", at_t0, t0, dt, YT0)
+
+    def newton_step_cl(self, at_t0, T1, *, t0, dt, Ycl0):
+        """... for cl given the new T (reference src/prob1base.py:3047-3080)."""
+        return self._newton(2, "cl", at_t0, t0, dt, Ycl0, T1)
+
+    def newton_step_cd(self, at_t0, T1, cl1, *, t0, dt, Ycd0):
+        """... for cd given the new T, cl (reference src/prob1base.py:3082-3115)."""
+        return self._newton(3, "cd", at_t0, t0, dt, Ycd0, T1, cl1)
+
     def step(self, at_t0: StateVars, *, t0, dt):
         assert dt > 0
         field, s = self._session()

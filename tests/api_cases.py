@@ -316,6 +316,57 @@ def check_hcs_denominator_value_error():
         integ.step(p1.state_from_mms_when(mms_case=case, t=0.0, grid=grid), t0=0.0, dt=0.1)
 
 
+def check_integrator_pieces(kind):
+    """The methods step() is made of (reference src/prob1base.py:2946-3115), called through the mirrored
+    integrator in step()'s order (:3117-3149), against the reference's results for the same calls and
+    against the mirrored step() itself."""
+    z = np.load(os.path.join(GOLDEN, "golden_substeps.npz"))
+    tag = f"{kind}/expsin_u8"
+    model = model_of("nb_a")
+    grid = p1.Grid(z[f"{tag}/x"], z[f"{tag}/y"])
+    case = p1mc.MMSCaseExpSin(grid=grid, model=model)
+    if kind == "reg":
+        forcing = p1.ForcingTerms_RegHCsTriple(mms_case=case, model=model, regularization_factor=ETA)
+        field = p1.SemiDiscreteField_RegHCsTriple(grid=grid, model=model, forcing_terms=forcing, regularization_factor=ETA)
+        integ = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple(field, regularization_factor=ETA)
+    elif kind == "cs3":
+        field = p1.SemiDiscreteField_CsTriple(grid=grid, model=model,
+                                              forcing_terms=p1.ForcingTerms_CsTriple(mms_case=case, model=model))
+        integ = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_CsTriple(field)
+    else:
+        field = p1.SemiDiscreteField_HCsTriple(grid=grid, model=model,
+                                               forcing_terms=p1.ForcingTerms_HCsTriple(mms_case=case, model=model))
+        integ = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_HCsTriple(field)
+    t0, dt = float(z[f"{tag}/t0"]), float(z[f"{tag}/dt"])
+    S0 = p1.state_from_mms_when(mms_case=case, t=t0, grid=grid)
+    tol = dict(rtol=0, atol=5e-14)
+    YT0 = dt * field.FT(S0, t0) + 2 * S0.T
+    Ycl0 = dt * field.Fcl(S0, t0) + 2 * S0.cl
+    Ycd0 = dt * field.Fcd(S0, t0) + 2 * S0.cd
+    np.testing.assert_allclose(YT0, z[f"{tag}/YT"], **tol)
+    cp1 = integ.initial_cp_pred(S0, t0, dt=dt)
+    cs1 = integ.initial_cs_pred(S0, t0, dt=dt)
+    np.testing.assert_allclose(cp1, z[f"{tag}/cp_pred"], **tol)
+    np.testing.assert_allclose(cs1, z[f"{tag}/cs_pred"], **tol)
+    lag = S0.with_changes(cp=cp1, T=S0.T, cl=S0.cl, cd=S0.cd, cs=cs1)
+    T1 = integ.newton_step_T(lag, t0=t0, dt=dt, YT0=YT0)
+    np.testing.assert_allclose(integ.last_residual["T"], z[f"{tag}/res_T"], rtol=0, atol=1e-13)
+    cl1 = integ.newton_step_cl(lag, T1, t0=t0, dt=dt, Ycl0=Ycl0)
+    cd1 = integ.newton_step_cd(lag, T1, cl1, t0=t0, dt=dt, Ycd0=Ycd0)
+    for a, name in ((T1, "T1"), (cl1, "cl1"), (cd1, "cd1")):
+        np.testing.assert_allclose(a, z[f"{tag}/{name}"], **tol)
+    assert set(integ.last_residual) == {"T", "cl", "cd"}
+    cpc = integ.corrector_cp_step(T1, cl1, cd1, at_t0=S0, t0=t0, dt=dt)
+    csc = integ.corrector_cs_step(T1, cl1, cd1, at_t0=S0, t0=t0, dt=dt)
+    np.testing.assert_allclose(cpc, z[f"{tag}/cp_corr"], **tol)
+    np.testing.assert_allclose(csc, z[f"{tag}/cs_corr"], **tol)
+    full = integ.step(S0, t0=t0, dt=dt)
+    for a, v in ((cpc, "cp"), (T1, "T"), (cl1, "cl"), (cd1, "cd"), (csc, "cs")):
+        np.testing.assert_allclose(a, getattr(full, v), rtol=0, atol=1e-15)
+    with pytest.raises(AssertionError):
+        integ.corrector_cp_step(T1, cl1, cd1, at_t0=S0, t0=t0, dt=0.0)
+
+
 def check_error_behaviour():
     model = model_of("nb_a")
     trial = reg_trial(p1mc.MMSCaseExpSin, model, 4)

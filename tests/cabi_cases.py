@@ -217,3 +217,64 @@ def check_hcs_denominator_error():
         raise AssertionError("no ValueError")
     ctx.get_stats()  # the condition is reported once
     ctx.close()
+
+
+# ---------------------------------------------------------------------------------- sub-steps
+REACT_OF = {"reg": _ffi.REACT_REGHCSTRIPLE, "cs3": _ffi.REACT_CSTRIPLE, "hcs": _ffi.REACT_HCSTRIPLE}
+
+
+def check_substeps(tag, streamed=False, options=None):
+    """Every piece of one predictor-corrector step called on its own through the C ABI, with the inputs the
+    reference passed between them.  Returns (max error of a result relative to the field scale, max absolute
+    error of a Newton residual).  streamed: forcing uploaded as arrays instead of evaluated in closed form."""
+    z = load("golden_substeps.npz")
+    kind = tag.split("/")[0]
+    cname = str(z[f"{tag}/case"])
+    rk = REACT_OF[kind]
+    ctx = make_ctx(z, tag, rk, CASE_ID[cname], CASE_PARAMS[cname])
+    for name, value in (options or {}).items():
+        ctx.set_option(name, value)
+    t0, dt = float(z[f"{tag}/t0"]), float(z[f"{tag}/dt"])
+    S0 = [z[f"{tag}/s0/{v}"] for v in VARS]
+    scale = max(np.max(np.abs(a)) for a in S0)
+    forcing = None
+    if streamed:
+        forcing = [ctx.eval_forcing(t0), ctx.eval_forcing(t0 + dt)]
+        ctx.close()
+        ctx = make_ctx(z, tag, rk, _ffi.MMS_STREAM)
+
+    def prepare(state):
+        ctx.set_state(*state)
+        if streamed:
+            ctx.set_forcing(0, *forcing[0])
+            ctx.set_forcing(1, *forcing[1])
+
+    worst, wres = 0.0, 0.0
+
+    def cmp(a, name):
+        nonlocal worst
+        worst = max(worst, np.max(np.abs(a - z[f"{tag}/{name}"])) / scale)
+
+    prepare(S0)
+    cp_pred, cs_pred = ctx.predict_cp_cs(t0, dt)
+    cmp(cp_pred, "cp_pred")
+    cmp(cs_pred, "cs_pred")
+    lag = [z[f"{tag}/cp_pred"], S0[1], S0[2], S0[3], z[f"{tag}/cs_pred"]]
+    prepare(lag)
+    T1, res = ctx.newton_step(1, t0, dt, z[f"{tag}/YT"])
+    cmp(T1, "T1")
+    wres = max(wres, np.max(np.abs(res - z[f"{tag}/res_T"])))
+    prepare(lag)
+    cl1, res = ctx.newton_step(2, t0, dt, z[f"{tag}/Ycl"], z[f"{tag}/T1"])
+    cmp(cl1, "cl1")
+    wres = max(wres, np.max(np.abs(res - z[f"{tag}/res_cl"])))
+    prepare(lag)
+    cd1, res = ctx.newton_step(3, t0, dt, z[f"{tag}/Ycd"], z[f"{tag}/T1"], z[f"{tag}/cl1"])
+    cmp(cd1, "cd1")
+    wres = max(wres, np.max(np.abs(res - z[f"{tag}/res_cd"])))
+    prepare(S0)
+    cp_c, cs_c = ctx.correct_cp_cs(t0, dt, z[f"{tag}/T1"], z[f"{tag}/cl1"], z[f"{tag}/cd1"])
+    cmp(cp_c, "cp_corr")
+    cmp(cs_c, "cs_corr")
+    ctx.close()
+    return worst, wres

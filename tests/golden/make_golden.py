@@ -18,6 +18,8 @@ The fixtures are plain data (inputs + the reference's outputs, float64 .npz and
                       for forward Euler and the predictor-corrector integrators
   golden_hcs.npz      the same three kinds of vectors for the HCsTriple (sharp Heaviside)
                       field, forcing terms and predictor-corrector integrator
+  golden_substeps.npz every piece of one predictor-corrector step called on its own
+                      (initial_*_pred, newton_step_*, corrector_*_step) for the three integrators
   golden_scalars.json MMSTrial.run_for_errors summaries (only with --scalars; slow)
   published_notebook_errors.json   numbers printed in the reference's executed
                       notebooks (parsed from the .ipynb stream outputs)
@@ -455,6 +457,64 @@ def gen_hcs():
 
 
 # ----------------------------------------------------------------------------------
+def gen_substeps():
+    """The methods step() is made of, called one by one in step()'s order (src/prob1base.py:3117-3149)."""
+    out = {}
+    eta = 50.0
+    kinds = {
+        "reg": (p1.SemiDiscreteField_RegHCsTriple, p1.ForcingTerms_RegHCsTriple,
+                p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple, {"regularization_factor": eta}),
+        "cs3": (p1.SemiDiscreteField_CsTriple, p1.ForcingTerms_CsTriple,
+                p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_CsTriple, {}),
+        "hcs": (p1.SemiDiscreteField_HCsTriple, p1.ForcingTerms_HCsTriple,
+                p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_HCsTriple, {}),
+    }
+    xu = np.linspace(0, 1, 9)
+    setups = [("expsin_u8", "expsin", "nb_a", xu, xu.copy(), 0.1, (1.0 / 8) ** 1.5),
+              ("pol_nu6x9", "pol", "stress", nonuniform_axis(6, 1.3, 0.2), nonuniform_axis(9, 0.8, -0.15), 0.0, 0.02)]
+    for kname, (field_cls, forcing_cls, integ_cls, common) in kinds.items():
+        for sname, cname, mname, x, y, t0, dt in setups:
+            tag = f"{kname}/{sname}"
+            grid = p1.Grid(x, y)
+            model = make_model(mname, 2)
+            case = MMS_CASES[cname][0](grid=grid, model=model)
+            forcing = forcing_cls(mms_case=case, model=model, **common)
+            field = field_cls(grid=grid, model=model, forcing_terms=forcing, **common)
+            integ = integ_cls(semi_discrete_field=field, **common)
+            S0 = p1.state_from_mms_when(mms_case=case, t=t0, grid=grid)
+            out[f"{tag}/x"], out[f"{tag}/y"] = x, y
+            out[f"{tag}/consts"] = consts_vec(mname)
+            out[f"{tag}/model_kind"] = np.array(2)
+            out[f"{tag}/eta"] = np.array(eta if kname == "reg" else 0.0)
+            out[f"{tag}/case"] = np.array(cname)
+            out[f"{tag}/t0"], out[f"{tag}/dt"] = np.array(t0), np.array(dt)
+            for v in ["cp", "T", "cl", "cd", "cs"]:
+                out[f"{tag}/s0/{v}"] = getattr(S0, v)
+            Y = {"T": dt * field.FT(S0, t0) + 2 * S0.T, "cl": dt * field.Fcl(S0, t0) + 2 * S0.cl,
+                 "cd": dt * field.Fcd(S0, t0) + 2 * S0.cd}
+            for v, a in Y.items():
+                out[f"{tag}/Y{v}"] = a
+            cp1 = integ.initial_cp_pred(S0, t0, dt=dt)
+            cs1 = integ.initial_cs_pred(S0, t0, dt=dt)
+            out[f"{tag}/cp_pred"], out[f"{tag}/cs_pred"] = cp1, cs1
+            lag = S0.with_changes(cp=cp1, T=S0.T, cl=S0.cl, cd=S0.cd, cs=cs1)
+            T1 = integ.newton_step_T(lag, t0=t0, dt=dt, YT0=Y["T"])
+            out[f"{tag}/T1"], out[f"{tag}/res_T"] = T1, integ.last_residual["T"]
+            cl1 = integ.newton_step_cl(lag, T1, t0=t0, dt=dt, Ycl0=Y["cl"])
+            out[f"{tag}/cl1"], out[f"{tag}/res_cl"] = cl1, integ.last_residual["cl"]
+            cd1 = integ.newton_step_cd(lag, T1, cl1, t0=t0, dt=dt, Ycd0=Y["cd"])
+            out[f"{tag}/cd1"], out[f"{tag}/res_cd"] = cd1, integ.last_residual["cd"]
+            out[f"{tag}/cp_corr"] = integ.corrector_cp_step(T1, cl1, cd1, at_t0=S0, t0=t0, dt=dt)
+            out[f"{tag}/cs_corr"] = integ.corrector_cs_step(T1, cl1, cd1, at_t0=S0, t0=t0, dt=dt)
+            full = integ.step(S0, t0=t0, dt=dt)
+            for v in ["cp", "T", "cl", "cd", "cs"]:  # the pieces really are the step
+                assert np.array_equal(getattr(full, v), out[f"{tag}/" + {"cp": "cp_corr", "T": "T1", "cl": "cl1",
+                                                                       "cd": "cd1", "cs": "cs_corr"}[v]])
+    np.savez_compressed(os.path.join(HERE, "golden_substeps.npz"), **out)
+    print("golden_substeps.npz:", len(out), "arrays")
+
+
+# ----------------------------------------------------------------------------------
 def gen_scalars(max_n_short=128, max_n_long=32):
     """MMSTrial.run_for_errors known answers on the notebooks' spatial-study schedule."""
     PC_REG = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple
@@ -534,7 +594,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     np.seterr(all="ignore")
-    todo = a.only.split(",") if a.only else ["ops", "mms", "steps", "hcs", "published"]
+    todo = a.only.split(",") if a.only else ["ops", "mms", "steps", "hcs", "substeps", "published"]
     if "ops" in todo:
         gen_ops()
     if "mms" in todo:
@@ -543,6 +603,8 @@ if __name__ == "__main__":
         gen_steps()
     if "hcs" in todo:
         gen_hcs()
+    if "substeps" in todo:
+        gen_substeps()
     if "published" in todo:
         gen_published()
     if a.scalars:

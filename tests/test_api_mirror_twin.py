@@ -78,3 +78,8 @@ def test_hcs_single_step_with_cs_ramp(cs_initial, cs_slope):
 
 def test_hcs_corrector_value_error():
     ac.check_hcs_denominator_value_error()
+
+
+@pytest.mark.parametrize("kind", ["reg", "cs3", "hcs"])
+def test_integrator_pieces_called_on_their_own(kind):
+    ac.check_integrator_pieces(kind)

@@ -82,3 +82,12 @@ def test_hcs_integrator_steps(tag):
 
 def test_hcs_corrector_reports_nonpositive_denominator():
     cc.check_hcs_denominator_error()
+
+
+# ---- the pieces of a predictor-corrector step called on their own
+@pytest.mark.parametrize("streamed", [False, True], ids=["closed_form", "streamed"])
+@pytest.mark.parametrize("tag", cc.tags("golden_substeps.npz", "/t0"))
+def test_substeps(tag, streamed):
+    err, res_err = cc.check_substeps(tag, streamed)
+    assert err < 5e-14, (tag, err)
+    assert res_err < 1e-13, (tag, res_err)
