@@ -142,7 +142,7 @@ def study_mesh_run(N=256, steps=400, warmup=20):
             "steps_per_s": steps / el, "ms_per_step": 1e3 * el / steps, "jacobi_sweeps": stats["sweeps"]}
 
 
-def cpu_baseline_run(N=256, steps=4):
+def cpu_baseline_run(N=256, steps=20):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import tedd_oracle as orc
     model = orc.Model(NB_A, 2)
