@@ -569,6 +569,133 @@ class ForcingTermsFromDict(ForcingTermsBase):
         return self._forcing_terms_dict["fcs"](t, xx, yy)
 
 
+# ------------------------------------------------------------------------------------------
+# MMS cases given as SymPy expressions, and forcing terms evaluated on the host for them
+#                                         reference src/prob1base.py:493-598, 1140-1347, 2313-2425
+# ------------------------------------------------------------------------------------------
+try:  # SymPy is only needed by MMSCaseSymbolic
+    import sympy as _sympy
+    t_sym, x_sym, y_sym = _sympy.symbols("t x y")
+except ImportError:  # pragma: no cover
+    _sympy = None
+    t_sym = x_sym = y_sym = None
+
+
+def _lambdify_txy(expr, t_var, x_var, y_var):
+    """(t, x, y) -> float64 array of the shape of x; a constant expression is broadcast
+    (reference src/prob1base.py:1140-1222).  DiracDelta(a) is 1 where |a| < 1e-13, else 0 (:1257)."""
+    mods = [{"DiracDelta": lambda a: np.where(np.abs(a) < 1e-13, 1.0, 0.0)}, "numpy"]
+    raw = _sympy.lambdify([t_var, x_var, y_var], expr, modules=mods)
+
+    def fn(t, xx, yy):
+        xx, yy = np.asarray(xx, dtype=float), np.asarray(yy, dtype=float)
+        assert xx.shape == yy.shape
+        val = np.asarray(raw(float(t), xx, yy), dtype=np.float64)
+        if val.size == 1:
+            return np.full(xx.shape, float(val.reshape(-1)[0]))
+        assert val.size == xx.size
+        return val.reshape(xx.shape)
+    return fn
+
+
+class MMSCaseSymbolic(MMSCaseBase):
+    """Exact solution given as SymPy expressions of (t, x, y); the derivatives the forcing terms need
+    are derived symbolically and lambdified for NumPy (reference src/prob1base.py:1225-1347).  The
+    library has no closed form for such a case: its forcing terms are evaluated on the host and their
+    arrays streamed to the device at every time level."""
+
+    def __init__(self, *, grid: Grid, model: DefaultModel01, cp_sym_expr, T_sym_expr, cl_sym_expr, cd_sym_expr,
+                 cs_sym_expr, t_var=None, x_var=None, y_var=None):
+        if _sympy is None:
+            raise ImportError("MMSCaseSymbolic needs sympy")
+        super().__init__(grid, model)
+        t_var = t_sym if t_var is None else t_var
+        x_var = x_sym if x_var is None else x_var
+        y_var = y_sym if y_var is None else y_var
+        exprs = {"cp": cp_sym_expr, "T": T_sym_expr, "cl": cl_sym_expr, "cd": cd_sym_expr, "cs": cs_sym_expr}
+        for var, expr in exprs.items():
+            expr = _sympy.sympify(expr)
+            dx, dy = _sympy.diff(expr, x_var), _sympy.diff(expr, y_var)
+            pack = {"": expr, "dt_": _sympy.diff(expr, t_var), "dx_": dx, "dy_": dy,
+                    "lap_": _sympy.diff(dx, x_var) + _sympy.diff(dy, y_var)}
+            for prefix, e in pack.items():
+                setattr(self, prefix + var, _lambdify_txy(e, t_var, x_var, y_var))
+
+
+def avg_int(f: Callable, grid: Grid):
+    """Average of f(x, y) over the cells [x_{i-1/2}, x_{i+1/2}] x [y_{j-1/2}, y_{j+1/2}] of the interior
+    nodes by 3x3 Gauss-Legendre quadrature; 0 on the boundary (reference src/prob1base.py:493-598)."""
+    w = np.array([5.0 / 9.0, 8.0 / 9.0, 5.0 / 9.0])
+    a = np.array([-np.sqrt(3.0 / 5.0), 0.0, np.sqrt(3.0 / 5.0)])
+    x, y = grid.x, grid.y
+    x_lo, wx = 0.5 * (x[:-2] + x[1:-1]), grid.h_phalf[1:-1]
+    y_lo, wy = 0.5 * (y[:-2] + y[1:-1]), grid.k_phalf[1:-1]
+    acc = np.zeros((grid.N - 1, grid.M - 1))
+    for i in range(3):
+        for j in range(3):
+            p, q = np.meshgrid(x_lo + (a[i] + 1.0) * 0.5 * wx, y_lo + (a[j] + 1.0) * 0.5 * wy, indexing="ij")
+            acc += w[i] * w[j] * f(p, q)
+    out = grid.make_full0()
+    out[1:-1, 1:-1] = 0.25 * acc
+    return out
+
+
+class _HostForcingTerms(ForcingTermsBase):
+    """Forcing terms of a manufactured solution evaluated with NumPy from the case's accessors
+    (cp, dt_cp, dx_cp, ... lap_cd, cs, dt_cs): fcp is the cell average of
+    d_t cp + cp (K1 (1 + cl) + K2 T), the others are nodal residuals of the exact solution
+    (reference src/prob1base.py:2313-2425; reaction gain g(cs) = cs | H_eta(cs) | (cs > 0):
+    :2875-2876, :3503-3551, :3222-3295).  Fields that use them stream the arrays to the device."""
+
+    def __init__(self, mms_case, model, reaction_kind, eta):
+        self._mms_case, self._model, self._react, self._eta = mms_case, model, reaction_kind, float(eta)
+
+    @property
+    def grid(self):
+        return self._mms_case.grid
+
+    def _gain(self, cs):
+        if self._react == _ffi.REACT_REGHCSTRIPLE:
+            return heaviside_regularized(cs, self._eta)
+        if self._react == _ffi.REACT_HCSTRIPLE:
+            return (np.asarray(cs) > 0).astype(float)
+        return np.asarray(cs, dtype=float)
+
+    def fcp_ptwise(self, t, xx, yy):
+        c, m = self._mms_case, self._model
+        cp = c.cp(t, xx, yy)
+        return c.dt_cp(t, xx, yy) + cp * (m.K1 * (1.0 + c.cl(t, xx, yy)) + m.K2 * c.T(t, xx, yy))
+
+    def fcp(self, t, xx=None, yy=None):
+        return avg_int(lambda p, q: self.fcp_ptwise(t, p, q), self.grid)
+
+    def fT(self, t, xx, yy):
+        c, m = self._mms_case, self._model
+        return c.dt_T(t, xx, yy) - (m.DT * c.lap_T(t, xx, yy) - m.K3 * c.cp(t, xx, yy) * c.T(t, xx, yy))
+
+    def fcl(self, t, xx, yy):
+        c, m = self._mms_case, self._model
+        cp, T, cl = c.cp(t, xx, yy), c.T(t, xx, yy), c.cl(t, xx, yy)
+        clx, cly = c.dx_cl(t, xx, yy), c.dy_cl(t, xx, yy)
+        return c.dt_cl(t, xx, yy) - (
+            m.Dl(cp, d=1) * (c.dx_cp(t, xx, yy) * clx + c.dy_cp(t, xx, yy) * cly) + m.Dl(cp) * c.lap_cl(t, xx, yy)
+            - m.V1(T) * clx - (cl + 1.0) * m.V1(T, d=1) * c.dx_T(t, xx, yy) - m.K4 * cp * (cl + 1.0))
+
+    def fcd(self, t, xx, yy):
+        c, m = self._mms_case, self._model
+        cp, T, cd = c.cp(t, xx, yy), c.T(t, xx, yy), c.cd(t, xx, yy)
+        dc, dT = m.Dd(cp, T, d=(1, 0)), m.Dd(cp, T, d=(0, 1))
+        return c.dt_cd(t, xx, yy) - (
+            (dc * c.dx_cp(t, xx, yy) + dT * c.dx_T(t, xx, yy)) * c.dx_cd(t, xx, yy)
+            + (dc * c.dy_cp(t, xx, yy) + dT * c.dy_T(t, xx, yy)) * c.dy_cd(t, xx, yy)
+            + m.Dd(cp, T) * c.lap_cd(t, xx, yy)
+            + m.Kd * (m.Sd - cd) * (c.cl(t, xx, yy) + 1.0) * self._gain(c.cs(t, xx, yy)))
+
+    def fcs(self, t, xx, yy):
+        c, m = self._mms_case, self._model
+        return c.dt_cs(t, xx, yy) + m.Kd * self._gain(c.cs(t, xx, yy)) * (1.0 + c.cl(t, xx, yy)) * (m.Sd - c.cd(t, xx, yy))
+
+
 class _DeviceForcingTerms(ForcingTermsBase):
     """MMS forcing terms evaluated by the device library from a closed-form MMS case:
     cell-averaged fcp (3x3 Gauss-Legendre, src/prob1base.py:493-598, 2313-2328) and nodal
@@ -577,10 +704,9 @@ class _DeviceForcingTerms(ForcingTermsBase):
     reaction_kind = None
 
     def __init__(self, *, mms_case: MMSCaseBase, model: DefaultModel01, eta=0.0):
-        if not isinstance(mms_case, MMSCaseDevice):
-            raise NotImplementedError(
-                "only the MMS cases built into the device library can be lowered; wrap other sources in "
-                "ForcingTermsFromDict so that their arrays are streamed to the device")
+        # a case the library has no closed form for: evaluate on the host, the field streams the arrays
+        self._host = None if isinstance(mms_case, MMSCaseDevice) else _HostForcingTerms(
+            mms_case, model, self.reaction_kind, eta)
         self._mms_case = mms_case
         self._model = model
         self._eta = float(eta)
@@ -600,6 +726,18 @@ class _DeviceForcingTerms(ForcingTermsBase):
         return self._model
 
     def _eval(self, t, xx, yy):
+        if self._host is not None:
+            g = self.grid
+            xx, yy = (g.xx, g.yy) if xx is None else (xx, yy)
+            key = ("host", float(t))
+            if key not in self._memo or not _same_nodes(g, xx, yy):
+                vals = [self._host.fcp(t), self._host.fT(t, xx, yy), self._host.fcl(t, xx, yy),
+                        self._host.fcd(t, xx, yy), self._host.fcs(t, xx, yy)]
+                if not _same_nodes(g, xx, yy):
+                    return vals
+                self._memo.clear()
+                self._memo[key] = vals
+            return self._memo[key]
         if not _same_nodes(self.grid, xx, yy):
             raise NotImplementedError("device forcing terms are evaluated at the nodes of their own grid")
         if self._session is None:
@@ -720,6 +858,8 @@ class _DeviceField(SemiDiscreteFieldBase):
         """The device forcing terms if every forcing callable still is its bound method."""
         ft = self._forcing_terms
         if not isinstance(ft, _DeviceForcingTerms) or ft.reaction_kind != self.reaction_kind:
+            return None
+        if ft._host is not None:  # no closed form in the library: host-evaluated, streamed
             return None
         if ft.grid is not self._grid or ft.model is not self._model:
             return None

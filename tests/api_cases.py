@@ -367,6 +367,65 @@ def check_integrator_pieces(kind):
         integ.corrector_cp_step(T1, cl1, cd1, at_t0=S0, t0=t0, dt=0.0)
 
 
+def check_symbolic_case_equals_builtin(kind):
+    """An MMSCaseSymbolic with the expressions of MMSCasePol (u = x(1-x) y(1-y) / (1+t) for all five,
+    reference src/prob1_mms_cases.py:151-186): its host-evaluated, streamed forcing terms and the steps
+    taken with them agree with the library's closed-form Pol case."""
+    sympy = pytest.importorskip("sympy")
+    model = model_of("nb_b")
+    grid = p1.Grid(np.linspace(0, 1, 9) ** 1.2, np.linspace(0, 1, 7))
+    u = p1.x_sym * (1 - p1.x_sym) * p1.y_sym * (1 - p1.y_sym) / (1 + p1.t_sym)
+    sym = p1.MMSCaseSymbolic(grid=grid, model=model, cp_sym_expr=u, T_sym_expr=u, cl_sym_expr=u, cd_sym_expr=u,
+                             cs_sym_expr=u)
+    pol = p1mc.MMSCasePol(grid=grid, model=model)
+    classes = {"reg": (p1.ForcingTerms_RegHCsTriple, p1.SemiDiscreteField_RegHCsTriple,
+                       p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple, {"regularization_factor": ETA}),
+               "cs3": (p1.ForcingTerms_CsTriple, p1.SemiDiscreteField_CsTriple,
+                       p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_CsTriple, {}),
+               "hcs": (p1.ForcingTerms_HCsTriple, p1.SemiDiscreteField_HCsTriple,
+                       p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_HCsTriple, {})}
+    F, Fld, Integ, common = classes[kind]
+    fa, fb = F(mms_case=sym, model=model, **common), F(mms_case=pol, model=model, **common)
+    for t in (0.0, 0.37):
+        for name in ("fcp", "fT", "fcl", "fcd", "fcs"):
+            np.testing.assert_allclose(getattr(fa, name)(t, grid.xx, grid.yy), getattr(fb, name)(t, grid.xx, grid.yy),
+                                       rtol=0, atol=1e-13, err_msg=f"{name} t={t}")
+    field_a = Fld(grid=grid, model=model, forcing_terms=fa, **common)
+    field_b = Fld(grid=grid, model=model, forcing_terms=fb, **common)
+    assert field_a._closed_form_source() is None and field_b._closed_form_source() is fb
+    ia, ib = Integ(field_a, **common), Integ(field_b, **common)
+    Sa = p1.state_from_mms_when(mms_case=sym, t=0.0, grid=grid)
+    Sb = p1.state_from_mms_when(mms_case=pol, t=0.0, grid=grid)
+    t, dt = 0.0, 0.02
+    for _ in range(3):
+        Sa, Sb = ia.step(Sa, t0=t, dt=dt), ib.step(Sb, t0=t, dt=dt)
+        t += dt
+    for v in ("cp", "T", "cl", "cd", "cs"):
+        np.testing.assert_allclose(getattr(Sa, v), getattr(Sb, v), rtol=0, atol=1e-14, err_msg=v)
+
+
+def check_symbolic_cs_ramp(cs_initial, cs_slope, dt=0.01):
+    """reference tests/test_time_integrator_hcs_triple_full_step.py:50-283 as written there: the ramp case
+    built with MMSCaseSymbolic and ForcingTerms_HCsTriple."""
+    pytest.importorskip("sympy")
+    mc = p1.ModelConsts(R0=8.3144621, Ea=1.60217662e-19, K1=1.52e-2, K2=1.52e-2, K3=1.52e-2, K4=1.52e-2,
+                        DT=1.22e-3, Dl_max=8.22e-4, phi_l=1.22e-5, gamma_T=1.22e-9, Kd=1.22e-8, Sd=15,
+                        Dd_max=2.62e-6, phi_d=1.22e-5, phi_T=1.60217662e-19 / 8.3144621, r_sp=5.22e-2, T_ref=303)
+    model = p1.DefaultModel01(mc=mc)
+    grid = p1.make_uniform_grid(N=4, M=4)
+    profile = p1.x_sym * (1 - p1.x_sym) * p1.y_sym * (1 - p1.y_sym)
+    case = p1.MMSCaseSymbolic(grid=grid, model=model, cp_sym_expr=0, T_sym_expr=0, cl_sym_expr=0, cd_sym_expr=0,
+                              cs_sym_expr=(cs_initial + cs_slope * p1.t_sym) * profile)
+    forcing = p1.ForcingTerms_HCsTriple(mms_case=case, model=model)
+    field = p1.SemiDiscreteField_HCsTriple(grid=grid, model=model, forcing_terms=forcing)
+    integ = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_HCsTriple(field, num_pc_steps=1, num_newton_steps=1)
+    S0 = p1.state_from_mms_when(mms_case=case, t=0.0, grid=grid)
+    S1 = integ.step(S0, t0=0.0, dt=dt)
+    for v in ("cp", "T", "cl", "cd"):
+        np.testing.assert_allclose(getattr(S1, v), getattr(case, v)(dt, grid.xx, grid.yy), rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(S1.cs, case.cs(dt, grid.xx, grid.yy), rtol=1e-6, atol=1e-12)
+
+
 def check_error_behaviour():
     model = model_of("nb_a")
     trial = reg_trial(p1mc.MMSCaseExpSin, model, 4)

@@ -83,3 +83,14 @@ def test_hcs_corrector_value_error():
 @pytest.mark.parametrize("kind", ["reg", "cs3", "hcs"])
 def test_integrator_pieces_called_on_their_own(kind):
     ac.check_integrator_pieces(kind)
+
+
+# ---- cases given as SymPy expressions: forcing evaluated on the host and streamed
+@pytest.mark.parametrize("kind", ["reg", "cs3", "hcs"])
+def test_symbolic_case_equals_builtin_case(kind):
+    ac.check_symbolic_case_equals_builtin(kind)
+
+
+@pytest.mark.parametrize("cs_initial,cs_slope", [(1.0, -0.5), (0.1, -15.0), (-0.2, -0.5)])
+def test_symbolic_cs_ramp_single_step(cs_initial, cs_slope):
+    ac.check_symbolic_cs_ramp(cs_initial, cs_slope)
