@@ -1,11 +1,14 @@
-"""The MMS case library of the reference (src/prob1_mms_cases.py) for the cases whose exact
-solutions are built into the device library: same class names and constructor arguments.
+"""The MMS case library of the reference (src/prob1_mms_cases.py): same class names and constructor
+arguments.
 
     import tedd.prob1_mms_cases as p1mc
     case = p1mc.MMSCaseExpSin(grid=grid, model=model)
 
-Each class only records which closed form to use and its parameters; the values (exact solution,
-its derivatives, and the forcing terms derived from them) are computed on the GPU.
+The classes derived from MMSCaseDevice only record which closed form of the device library to use and
+its parameters; the values (exact solution, its derivatives, and the forcing terms derived from them)
+are computed on the GPU.  The classes derived from MMSCaseSymbolic (StiffExpDecay,
+PolWithOscilatingTime, CsZeroCrossing) state their solution as SymPy expressions; their forcing terms
+are evaluated on the host and streamed to the device at every time level.
 """
 from __future__ import annotations
 
@@ -13,8 +16,71 @@ from typing import List
 
 import numpy as np
 
+try:
+    import sympy
+except ImportError:  # only the symbolic cases need it
+    sympy = None
+
 from . import _ffi
 from . import prob1base as p1
+
+
+def _unit_square_bubble():
+    return p1.x_sym * (1 - p1.x_sym) * p1.y_sym * (1 - p1.y_sym)
+
+
+class MMSCaseStiffExpDecay(p1.MMSCaseSymbolic):
+    """u_v = x(1-x) y(1-y) e^{-a_v t} with decay rates a_cl = a_base, a_T = a_base/10,
+    a_cd = a_cs = a_base/100, a_cp = a_base/1000: one spatial profile, time scales a decade apart
+    (reference src/prob1_mms_cases.py:12-63)."""
+
+    def __init__(self, grid: p1.Grid, model: p1.DefaultModel01, *, a_base: float = 1.0):
+        W, t = _unit_square_bubble(), p1.t_sym
+        rate = {"cl": a_base, "T": a_base / 10.0, "cd": a_base / 100.0, "cs": a_base / 100.0,
+                "cp": a_base / 1000.0}
+        sol = {v: W * sympy.exp(-a * t) for v, a in rate.items()}
+        super().__init__(grid=grid, model=model, cp_sym_expr=sol["cp"], T_sym_expr=sol["T"],
+                         cl_sym_expr=sol["cl"], cd_sym_expr=sol["cd"], cs_sym_expr=sol["cs"])
+
+
+def make_MMSCaseStiffExpDecay_cls(ref_speed):
+    class the_MMSCaseStiffExpDecay(MMSCaseStiffExpDecay):
+        def __init__(self, grid: p1.Grid, model: p1.DefaultModel01):
+            super().__init__(grid=grid, model=model, a_base=ref_speed)
+
+    return the_MMSCaseStiffExpDecay
+
+
+class MMSCasePolWithOscilatingTime(p1.MMSCaseSymbolic):
+    """All five unknowns equal ampl (1 + shrink sin(speed t)) x(1-x) y(1-y); non-negative for
+    ampl > 0 and shrink in (0, 1] (reference src/prob1_mms_cases.py:76-134)."""
+
+    def __init__(self, grid: p1.Grid, model: p1.DefaultModel01, *, ampl: float = 1, speed: float = 1,
+                 shrink: float = 1):
+        u = ampl * (1 + shrink * sympy.sin(speed * p1.t_sym)) * _unit_square_bubble()
+        super().__init__(grid=grid, model=model, cp_sym_expr=u, T_sym_expr=u, cl_sym_expr=u, cd_sym_expr=u,
+                         cs_sym_expr=u)
+
+
+def make_MMSCasePolWithOscilatingTime_cls(*, ampl, speed):
+    class the_MMSCasePolWithOscilatingTime(MMSCasePolWithOscilatingTime):
+        def __init__(self, grid: p1.Grid, model: p1.DefaultModel01):
+            super().__init__(grid=grid, model=model, ampl=ampl, speed=speed)
+
+    return the_MMSCasePolWithOscilatingTime
+
+
+class MMSCaseCsZeroCrossing(p1.MMSCaseSymbolic):
+    """cp = T = cl = cd = 0 and cs = (cs_A - cs_B t) W(x, y), which changes sign at t = cs_A / cs_B;
+    W defaults to x(1-x) y(1-y) (reference src/prob1_mms_cases.py:341-392)."""
+
+    def __init__(self, grid: p1.Grid, model: p1.DefaultModel01, *, cs_A: float = 0.5, cs_B: float = 1.0,
+                 spatial_profile_expr=None):
+        W = _unit_square_bubble() if spatial_profile_expr is None else spatial_profile_expr
+        zero = sympy.S(0)
+        cs = (sympy.Float(cs_A) - sympy.Float(cs_B) * p1.t_sym) * W
+        super().__init__(grid=grid, model=model, cp_sym_expr=zero, T_sym_expr=zero, cl_sym_expr=zero,
+                         cd_sym_expr=zero, cs_sym_expr=cs)
 
 
 class MMSCasePol(p1.MMSCaseDevice):

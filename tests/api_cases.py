@@ -24,6 +24,14 @@ CASES = {
     "peaks_fast1e1": (p1mc.MMSCaseSlowlyChangingPeaks_Fast1e1, "nb_b", 1.0),
     "nfs_h2_h3": (p1mc.MMSCaseNonFullySmoothPol_cpcsH2_TclcdH3, "nb_a", 1.0),
 }
+# cases stated symbolically (forcing evaluated on the host and streamed); sympy is optional
+if p1mc.sympy is not None:
+    CASES.update({
+        "cs_zero_crossing": (p1mc.MMSCaseCsZeroCrossing, "nb_b", 1.0),
+        "stiff_exp_decay": (p1mc.MMSCaseStiffExpDecay, "nb_b", 1.0),
+        "pol_oscillating": (p1mc.make_MMSCasePolWithOscilatingTime_cls(ampl=1.0, speed=10.0), "nb_b", 1.0),
+    })
+SYMBOLIC_CASES = ["cs_zero_crossing", "stiff_exp_decay", "pol_oscillating"]
 
 
 def model_of(name, kind=2):
@@ -424,6 +432,54 @@ def check_symbolic_cs_ramp(cs_initial, cs_slope, dt=0.01):
     for v in ("cp", "T", "cl", "cd"):
         np.testing.assert_allclose(getattr(S1, v), getattr(case, v)(dt, grid.xx, grid.yy), rtol=1e-8, atol=1e-12)
     np.testing.assert_allclose(S1.cs, case.cs(dt, grid.xx, grid.yy), rtol=1e-6, atol=1e-12)
+
+
+def check_symbolic_library_case_golden(cname, kname):
+    """The library cases stated only as SymPy expressions (reference src/prob1_mms_cases.py:12-148,
+    :341-392), built through the mirrored classes: forcing arrays at two times and 1/2/4
+    predictor-corrector steps against vectors of the reference itself (tests/golden/make_golden.py,
+    gen_symbolic), for the three reaction kinds."""
+    pytest.importorskip("sympy")
+    z = np.load(os.path.join(GOLDEN, "golden_symbolic.npz"))
+    g = lambda k: z[f"{cname}/{k}"]
+    par = {k.split("/")[-1]: float(z[k]) for k in z.files if k.startswith(f"{cname}/param/")}
+    ctor = {"stiff_exp_decay": p1mc.MMSCaseStiffExpDecay, "pol_oscillating": p1mc.MMSCasePolWithOscilatingTime,
+            "cs_zero_crossing": p1mc.MMSCaseCsZeroCrossing}[cname]
+    consts = dict(zip(p1.ModelConsts._fields, g("consts")))
+    model = p1.DefaultModel02(p1.ModelConsts(**consts))
+    grid = p1.Grid(g("x"), g("y"))
+    case = ctor(grid=grid, model=model, **par)
+    eta = float(g("eta"))
+    common = {"regularization_factor": eta} if kname == "reg" else {}
+    field_cls, forcing_cls, integ_cls = {
+        "reg": (p1.SemiDiscreteField_RegHCsTriple, p1.ForcingTerms_RegHCsTriple,
+                p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple),
+        "cst": (p1.SemiDiscreteField_CsTriple, p1.ForcingTerms_CsTriple,
+                p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_CsTriple),
+        "hcs": (p1.SemiDiscreteField_HCsTriple, p1.ForcingTerms_HCsTriple,
+                p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_HCsTriple)}[kname]
+    forcing = forcing_cls(mms_case=case, model=model, **common)
+    for it in (0, 1):
+        t = float(g(f"{kname}/t{it}/t"))
+        for v in ("fcp", "fT", "fcl", "fcd", "fcs"):
+            np.testing.assert_allclose(getattr(forcing, v)(t, grid.xx, grid.yy), g(f"{kname}/t{it}/{v}"),
+                                       rtol=1e-12, atol=1e-15, err_msg=f"{cname}/{kname}/{v}@{t}")
+    field = field_cls(grid=grid, model=model, forcing_terms=forcing, **common)
+    integ = integ_cls(field, **common)
+    t, dt = float(g(f"{kname}/steps/t0")), float(g(f"{kname}/steps/dt"))
+    S = p1.state_from_mms_when(mms_case=case, t=t, grid=grid)
+    for v in ("cp", "T", "cl", "cd", "cs"):
+        np.testing.assert_allclose(getattr(S, v), g(f"{kname}/steps/s0/{v}"), rtol=1e-13, atol=1e-16)
+    for k in range(1, 5):
+        S = integ.step(S, t0=t, dt=dt)
+        t += dt
+        if k in (1, 2, 4):
+            for v in ("cp", "T", "cl", "cd", "cs"):
+                np.testing.assert_allclose(getattr(S, v), g(f"{kname}/steps/s{k}/{v}"), rtol=1e-11, atol=1e-15,
+                                           err_msg=f"{cname}/{kname}/s{k}/{v}")
+            for v in ("T", "cl", "cd"):
+                np.testing.assert_allclose(integ.last_residual[v], g(f"{kname}/steps/s{k}/res_{v}"),
+                                           rtol=1e-6, atol=1e-13, err_msg=f"{cname}/{kname}/s{k}/res_{v}")
 
 
 def check_error_behaviour():

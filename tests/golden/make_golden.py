@@ -20,6 +20,8 @@ The fixtures are plain data (inputs + the reference's outputs, float64 .npz and
                       field, forcing terms and predictor-corrector integrator
   golden_substeps.npz every piece of one predictor-corrector step called on its own
                       (initial_*_pred, newton_step_*, corrector_*_step) for the three integrators
+  golden_symbolic.npz forcing arrays and integrator steps for the three cases the reference states
+                      symbolically only (StiffExpDecay, PolWithOscilatingTime, CsZeroCrossing)
   golden_scalars.json MMSTrial.run_for_errors summaries (only with --scalars; slow)
   published_notebook_errors.json   numbers printed in the reference's executed
                       notebooks (parsed from the .ipynb stream outputs)
@@ -457,6 +459,57 @@ def gen_hcs():
 
 
 # ----------------------------------------------------------------------------------
+def symbolic_cases():
+    return {
+        "stiff_exp_decay": (lambda grid, model: p1mc.MMSCaseStiffExpDecay(grid=grid, model=model, a_base=50.0),
+                            dict(a_base=50.0), 0.0),
+        "pol_oscillating": (p1mc.make_MMSCasePolWithOscilatingTime_cls(ampl=0.7, speed=12.0),
+                            dict(ampl=0.7, speed=12.0), 0.0),
+        # starts just before the sign change of cs at t = cs_A / cs_B = 0.5
+        "cs_zero_crossing": (p1mc.MMSCaseCsZeroCrossing, {}, 0.49),
+    }
+
+
+def gen_symbolic():
+    """The cases that exist only as SymPy expressions in the reference: forcing arrays of the three
+    reaction kinds at two times, and 1/2/4 predictor-corrector steps per kind."""
+    out = {}
+    x, y = np.linspace(0, 1, 9), nonuniform_axis(7, 0.9, -0.1)
+    eta = 1e-3
+    kinds = {
+        "reg": (p1.SemiDiscreteField_RegHCsTriple, p1.ForcingTerms_RegHCsTriple,
+                p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple, {"regularization_factor": eta}),
+        "cst": (p1.SemiDiscreteField_CsTriple, p1.ForcingTerms_CsTriple,
+                p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_CsTriple, {}),
+        "hcs": (p1.SemiDiscreteField_HCsTriple, p1.ForcingTerms_HCsTriple,
+                p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_HCsTriple, {}),
+    }
+    for cname, (cls, params, t0) in symbolic_cases().items():
+        tag = f"{cname}"
+        out[f"{tag}/x"], out[f"{tag}/y"] = x, y
+        out[f"{tag}/consts"] = consts_vec("nb_b")
+        out[f"{tag}/eta"] = np.array(eta)
+        out[f"{tag}/t0"] = np.array(t0)
+        out[f"{tag}/dt"] = np.array(5e-3)
+        for k, v in params.items():
+            out[f"{tag}/param/{k}"] = np.array(v)
+        for kname, (field_cls, forcing_cls, integ_cls, common) in kinds.items():
+            grid = p1.Grid(x.copy(), y.copy())
+            model = make_model("nb_b", 2)
+            trial = mtu.MMSTrial(grid=grid, model=model, mms_case_cls=cls, field_cls=field_cls,
+                                 forcing_terms_cls=forcing_cls, integrator_cls=integ_cls,
+                                 integrator_params=dict(common), forcing_terms_params=dict(common),
+                                 field_params=dict(common))
+            for it, t in enumerate([t0, t0 + 0.013]):
+                out[f"{tag}/{kname}/t{it}/t"] = np.array(t)
+                for v in ["fcp", "fT", "fcl", "fcd", "fcs"]:
+                    out[f"{tag}/{kname}/t{it}/{v}"] = getattr(trial.forcing_terms, v)(t, grid.xx, grid.yy)
+            _record_steps(out, f"{tag}/{kname}/steps", trial, t0, 5e-3, [1, 2, 4], True)
+    np.savez_compressed(os.path.join(HERE, "golden_symbolic.npz"), **out)
+    print("golden_symbolic.npz:", len(out), "arrays")
+
+
+# ----------------------------------------------------------------------------------
 def gen_substeps():
     """The methods step() is made of, called one by one in step()'s order (src/prob1base.py:3117-3149)."""
     out = {}
@@ -594,7 +647,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     np.seterr(all="ignore")
-    todo = a.only.split(",") if a.only else ["ops", "mms", "steps", "hcs", "substeps", "published"]
+    todo = a.only.split(",") if a.only else ["ops", "mms", "steps", "hcs", "substeps", "symbolic", "published"]
     if "ops" in todo:
         gen_ops()
     if "mms" in todo:
@@ -605,6 +658,8 @@ if __name__ == "__main__":
         gen_hcs()
     if "substeps" in todo:
         gen_substeps()
+    if "symbolic" in todo:
+        gen_symbolic()
     if "published" in todo:
         gen_published()
     if a.scalars:

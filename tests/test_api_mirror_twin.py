@@ -66,9 +66,24 @@ def test_error_behaviour():
 
 
 # ---- HCsTriple (sharp Heaviside) through the mirrored classes
-@pytest.mark.parametrize("case", ["pol", "expsin", "peaks_fast1e1"])
+@pytest.mark.parametrize("case", ["pol", "expsin", "peaks_fast1e1"] + ac.SYMBOLIC_CASES)
 def test_hcs_newton_residuals(case):
+    if case not in ac.CASES:
+        pytest.skip("needs sympy")
     ac.check_hcs_newton_residuals(case)
+
+
+@pytest.mark.parametrize("kname", ["reg", "cst", "hcs"])
+@pytest.mark.parametrize("cname", ac.SYMBOLIC_CASES)
+def test_symbolic_library_case_golden(cname, kname):
+    ac.check_symbolic_library_case_golden(cname, kname)
+
+
+@pytest.mark.parametrize("case", ac.SYMBOLIC_CASES)
+def test_newton_residuals_symbolic_cases(case):
+    if case not in ac.CASES:
+        pytest.skip("needs sympy")
+    ac.check_newton_residuals(case)
 
 
 @pytest.mark.parametrize("cs_initial,cs_slope", [(1.0, -0.5), (0.1, -10.0), (0.1, -15.0), (-0.2, -0.5), (0.0, -5.0)])
