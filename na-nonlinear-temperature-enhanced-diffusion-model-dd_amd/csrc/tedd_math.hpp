@@ -63,6 +63,24 @@ TEDD_HD double tedd_div(double a, double b) {
     return a / b;
 }
 
+// Accesses to arrays a kernel touches exactly once per node (outputs, forcing values): marked
+// non-temporal on the device so they do not displace the stencil rows that neighbouring tiles
+// re-read from L2.
+TEDD_HD void put_once(double* p, double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+TEDD_HD double get_once(const double* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 // ---------------------------------------------------------------- constitutive laws
 TEDD_HD double law_Dl(const ModelC& m, double c) { return m.Dl_max * tedd_exp(-m.phi_l * c); }
 TEDD_HD double law_V1(const ModelC& m, double T) { return m.gamma_T * T; }

@@ -62,11 +62,11 @@ TEDD_HD Forcing5 node_forcing(const ModelC& m, const MmsTabs& tb, const ForcingS
     Forcing5 r;
     if (CASE == CASE_STREAM) {
         const size_t c = at(g, li, j);
-        r.fcp = src.f[0][c];
-        r.fT = src.f[1][c];
-        r.fcl = src.f[2][c];
-        r.fcd = src.f[3][c];
-        r.fcs = src.f[4][c];
+        r.fcp = get_once(src.f[0] + c);
+        r.fT = get_once(src.f[1] + c);
+        r.fcl = get_once(src.f[2] + c);
+        r.fcd = get_once(src.f[3] + c);
+        r.fcs = get_once(src.f[4] + c);
     } else {
         const MmsPt p = mms_node<CASE>(m, src.tm, tb, li, j);
         r.fT = mms_fT(m, p);
@@ -174,9 +174,9 @@ struct PredictFn {
         const double cp0 = S.v[VAR_CP][c], T0 = S.v[VAR_T][c], cl0 = S.v[VAR_CL][c], cd0 = S.v[VAR_CD][c],
                      cs0 = S.v[VAR_CS][c];
         const double YTv = dt * F.T + 2.0 * T0;
-        YT[c] = YTv;
-        Ycl[c] = dt * F.cl + 2.0 * cl0;
-        Ycd[c] = dt * F.cd + 2.0 * cd0;
+        put_once(YT + c, YTv);
+        put_once(Ycl + c, dt * F.cl + 2.0 * cl0);
+        put_once(Ycd + c, dt * F.cd + 2.0 * cd0);
         // forcing at t1: only fcp (cell average) and fcs are needed here
         double fcp1, fcs1, fT1 = 0.0;
         if (CASE == CASE_STREAM && FCASE != CASE_STREAM) {
@@ -184,15 +184,15 @@ struct PredictFn {
             fcp1 = fb.fcp;
             fcs1 = fb.fcs;
             fT1 = fb.fT;
-            f1_out.v[0][c] = fb.fcp;
-            f1_out.v[1][c] = fb.fT;
-            f1_out.v[2][c] = fb.fcl;
-            f1_out.v[3][c] = fb.fcd;
-            f1_out.v[4][c] = fb.fcs;
+            put_once(f1_out.v[0] + c, fb.fcp);
+            put_once(f1_out.v[1] + c, fb.fT);
+            put_once(f1_out.v[2] + c, fb.fcl);
+            put_once(f1_out.v[3] + c, fb.fcd);
+            put_once(f1_out.v[4] + c, fb.fcs);
         } else if (CASE == CASE_STREAM) {
-            fcp1 = f1.f[0][c];
-            fcs1 = f1.f[4][c];
-            if (bT) fT1 = f1.f[1][c];
+            fcp1 = get_once(f1.f[0] + c);
+            fcs1 = get_once(f1.f[4] + c);
+            if (bT) fT1 = get_once(f1.f[1] + c);
         } else {
             const MmsPt p1 = mms_node<CASE>(m, f1.tm, tb, li, j);
             fcs1 = mms_fcs<REACT>(m, p1);
@@ -205,7 +205,7 @@ struct PredictFn {
         const double cps = cp0 + dt * F.cp;
         const double Fcps = fcp1 + (in ? rhs_cp(m, cps, T0, cl0) : 0.0);
         const double cp1v = cp0 + 0.5 * dt * (F.cp + Fcps);
-        cp1[c] = cp1v;
+        put_once(cp1 + c, cp1v);
         if (bT) {  // same arithmetic as newton_rhs_value<VAR_T> / newton_row<VAR_T>
             double bv = 0.0;
             if (in) {
@@ -214,24 +214,24 @@ struct PredictFn {
                 const double r = YTv - (2.0 * T.c - dt * (fT1 + rhs_T(m, ge, T, cp1v)));
                 bv = tedd_div(r, 2.0 - dt * jac_T_FT(m, ge, cp1v).c);
             }
-            bT[c] = bv;
+            put_once(bT + c, bv);
         }
         // Heun for cs
         const double css = cs0 + dt * F.cs;
         const double Fcss = in ? (fcs1 - reaction<REACT>(m, cl0, cd0, css)) : 0.0;
         const double v = cs0 + (0.5 * dt) * (F.cs + Fcss);
-        cs1[c] = (REACT != REACT_CS3) ? (in ? v : 0.0 * v) : v;  // RegHCs/HCs: times the interior mask (:3645, :3374)
+        put_once(cs1 + c, (REACT != REACT_CS3) ? (in ? v : 0.0 * v) : v);  // RegHCs/HCs: times the interior mask (:3645, :3374)
         // corrector inputs
         const double h = dt / 2;
         const double al0 = -m.K2 * T0 - m.K1 * (cl0 + 1.0);
-        ncp[c] = in ? (1.0 + h * al0) * cp0 + h * (fa.fcp + fcp1) : 0.0;
+        put_once(ncp + c, in ? (1.0 + h * al0) * cp0 + h * (fa.fcp + fcp1) : 0.0);
         if (REACT == REACT_REG) {
-            ycs[c] = 2.0 * cs0 - dt * m.Kd * (m.Sd - cd0) * (cl0 + 1.0) * heaviside_reg(cs0, m.eta) + dt * (fa.fcs + fcs1);
+            put_once(ycs + c, 2.0 * cs0 - dt * m.Kd * (m.Sd - cd0) * (cl0 + 1.0) * heaviside_reg(cs0, m.eta) + dt * (fa.fcs + fcs1));
         } else if (REACT == REACT_HCS) {
-            ycs[c] = 2.0 * cs0 + dt * F.cs + dt * fcs1;  // Y0 of the sign-case corrector (:3412)
+            put_once(ycs + c, 2.0 * cs0 + dt * F.cs + dt * fcs1);  // Y0 of the sign-case corrector (:3412)
         } else {
             const double b0 = -m.Kd * (m.Sd - cd0) * (1.0 + cl0);
-            ycs[c] = in ? (1.0 + h * b0) * cs0 + h * (fa.fcs + fcs1) : 0.0;
+            put_once(ycs + c, in ? (1.0 + h * b0) * cs0 + h * (fa.fcs + fcs1) : 0.0);
         }
     }
 };
