@@ -82,7 +82,9 @@ int tedd_set_model(tedd_ctx* ctx, const double consts[17], int32_t model_kind, d
 /* Execution options (no counterpart in the reference; they select between implementations that give
  * the same results).  "strip_solve" (default 1): solve the Newton systems with the register-resident
  * kernel chain (several Jacobi sweeps per launch) instead of one launch per sweep; "strip_hmax": sweeps
- * per launch (0 = automatic, at most 16); "cache_forcing" (default 1): evaluate the closed-form MMS
+ * per launch (0 = automatic, at most 16); "strip_shape" (default -1: by mesh size and system; 0: 64-row tiles
+ * of 4 strips, 1: 32-row tiles of 8 short strips for meshes too small to fill the GPU, 2: 48-row tiles of 12
+ * short strips); "cache_forcing" (default 1): evaluate the closed-form MMS
  * forcing once per time level into arrays instead of inside the step kernels; "fuse_forcing" (default -1:
  * slabs of at most 4 M nodes): those arrays are made by the predictor launch instead of a launch of their own. */
 int tedd_set_option(tedd_ctx* ctx, const char* name, double value);

@@ -708,6 +708,7 @@ public:
     // options
     int opt_strip = 1;      // 1: register-resident solve chain (backends that have it); 0: one launch per sweep
     int opt_strip_hmax = 0;         // sweeps fused per launch (0 = automatic)
+    int opt_strip_shape = -1;       // tile shape of the chain: -1 by mesh size and system, 0: 64 rows, 1: 32 rows, 2: 48 rows
     bool bT_ready = false;    // slot DA holds rhs/diag of the next T system (written by the predictor launch)
 
     // Register-resident solve chain (tedd_strip.hpp): b = delta^1 = rhs/diag from the node kernel,
@@ -770,10 +771,10 @@ public:
                 A.d_out = dout;
                 A.u_out = lastl ? unew : nullptr;
                 if (lastl) {
-                    be.template solve_strip<VAR, REACT, true>(fam, A, ncols);
+                    be.template solve_strip<VAR, REACT, true>(fam, A, ncols, opt_strip_shape);
                     mark(unew, r);
                 } else {
-                    be.template solve_strip<VAR, REACT, false>(fam, A, ncols);
+                    be.template solve_strip<VAR, REACT, false>(fam, A, ncols, opt_strip_shape);
                     mark(dout, r);
                 }
                 din = dout;
@@ -1157,6 +1158,8 @@ public:
             opt_strip = value != 0.0;
         else if (name == "strip_hmax")
             opt_strip_hmax = (int)value;
+        else if (name == "strip_shape")
+            opt_strip_shape = (int)value;
         else if (name == "cache_forcing")
             opt_cache_forcing = value != 0.0;
         else if (name == "fuse_forcing")

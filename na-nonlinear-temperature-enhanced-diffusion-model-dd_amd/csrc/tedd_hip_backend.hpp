@@ -257,6 +257,7 @@ struct HipBackend {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int device = -1;
+    int num_cus = 256;
     double* d_partials = nullptr;
     unsigned long long* d_csstats = nullptr;  // [4096] max, [4096] min
     bool profiling = false;
@@ -274,6 +275,7 @@ struct HipBackend {
         TEDD_HIP(hipGetDevice(&cur));
         device = (dev >= 0) ? dev : cur;
         TEDD_HIP(hipSetDevice(device));
+        TEDD_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, device));
         TEDD_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         own_stream = true;
         d_partials = (double*)alloc((size_t)kMaxReduceBlocks * 8 * sizeof(double));
@@ -423,18 +425,42 @@ struct HipBackend {
         TEDD_HIP(hipGetLastError());
     }
     // one launch of the register-resident Newton solve chain (tedd_strip.hpp)
+    // shape: SHAPE_LARGE / SHAPE_SMALL / SHAPE_MID, or -1 = by mesh size and system: small tiles when
+    // the large ones would leave compute units without work (fewer than 2 tiles per unit); otherwise
+    // large tiles for T and 48-row tiles for cl and cd (tedd_strip.hpp, StripShape).  A shape whose
+    // tile the depth H does not fit falls back to the large one.
     template <int VAR, int REACT, bool LAST>
-    void solve_strip(int fam, StripArgs A, int ncols) {
+    void solve_strip(int fam, StripArgs A, int ncols, int shape = -1) {
         if (A.r1 <= A.r0) return;
         if (A.H < 0 || A.H > 16 || A.nsweeps < 0 || A.nsweeps > A.H) throw std::runtime_error("bad strip-solve depth");
         if (A.b_in == nullptr || A.d_in == nullptr) throw std::runtime_error("strip solve needs rhs and delta^1");
         Scope sc(this, fam);
-        const int TIR = kSTile - 2 * A.H, TIC = kSTile - 2 * strip_col_halo(A.H);
+        const int TIC = kSTile - 2 * strip_col_halo(A.H);
         A.tiles_x = (ncols + TIC - 1) / TIC;
-        const long long nt = (long long)A.tiles_x * ((A.r1 - A.r0 + TIR - 1) / TIR);
+        auto n_tiles = [&](int sh) {
+            const int TIR = strip_tile_rows(sh) - 2 * A.H;
+            return (long long)A.tiles_x * ((A.r1 - A.r0 + TIR - 1) / TIR);
+        };
+        const bool small_fits = strip_tile_rows(SHAPE_SMALL) - 2 * A.H >= 8;
+        const bool mid_fits = strip_tile_rows(SHAPE_MID) - 2 * A.H >= 8;
+        if (shape < 0) {
+            if (small_fits && n_tiles(SHAPE_LARGE) < 2LL * num_cus)
+                shape = SHAPE_SMALL;
+            else
+                shape = (VAR != VAR_T && A.H <= 8) ? SHAPE_MID : SHAPE_LARGE;
+        }
+        if ((shape == SHAPE_SMALL && !small_fits) || (shape == SHAPE_MID && !mid_fits)) shape = SHAPE_LARGE;
+        const long long nt = n_tiles(shape);
         if (nt > 0x7fffffffLL) throw std::runtime_error("mesh too large for the tile index");
-        hipLaunchKernelGGL((k_solve_strip<VAR, REACT, LAST>), dim3((unsigned)nt), dim3(kSTile, StripShape<VAR>::W), 0,
-                           stream, A);
+        if (shape == SHAPE_SMALL)
+            hipLaunchKernelGGL((k_solve_strip<VAR, REACT, LAST, SHAPE_SMALL>), dim3((unsigned)nt),
+                               dim3(kSTile, StripShape<VAR, SHAPE_SMALL>::W), 0, stream, A);
+        else if (shape == SHAPE_MID)
+            hipLaunchKernelGGL((k_solve_strip<VAR, REACT, LAST, SHAPE_MID>), dim3((unsigned)nt),
+                               dim3(kSTile, StripShape<VAR, SHAPE_MID>::W), 0, stream, A);
+        else
+            hipLaunchKernelGGL((k_solve_strip<VAR, REACT, LAST, SHAPE_LARGE>), dim3((unsigned)nt),
+                               dim3(kSTile, StripShape<VAR, SHAPE_LARGE>::W), 0, stream, A);
         TEDD_HIP(hipGetLastError());
     }
     template <int CASE, int REACT>

@@ -120,6 +120,7 @@ TEDD_HD double reaction_gain(const ModelC& m, double cs) {
 // R = Kd g(cs) (1+cl) (Sd-cd)   (interior nodes only; callers apply the mask)
 template <int REACT>
 TEDD_HD double reaction(const ModelC& m, double cl, double cd, double cs) {
+#pragma clang fp contract(off)  // see node_field: the cs path is evaluated without fused multiply-adds
     return (1.0 + cl) * (m.Sd - cd) * (m.Kd * reaction_gain<REACT>(m, cs));
 }
 

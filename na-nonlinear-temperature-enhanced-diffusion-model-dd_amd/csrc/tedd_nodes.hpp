@@ -98,7 +98,14 @@ TEDD_HD F5 node_field(const ModelC& m, const GridDev& g, const Fields5& S, const
         F.T += rhs_T(m, ge, T, cp.c);
         F.cl += rhs_cl(m, ge, faces_Dl(m, cp), T, cl, cp.c);
         F.cd += rhs_cd_diffusion(ge, faces_Dd(m, cp, T), cd) + R;
-        F.cs = f.fcs - R;
+        {
+            // The sign of cs switches the sharp Heaviside gain, and manufactured solutions make cs pass
+            // through zero exactly (reference tests/test_time_integrator_hcs_triple_full_step.py:133-283):
+            // every operation on the cs path (here and in the cs predictor) is rounded on its own, as in the
+            // reference's NumPy expressions, so that a cancellation to zero there is one here too.
+#pragma clang fp contract(off)
+            F.cs = f.fcs - R;
+        }
     }
     return F;
 }
@@ -217,9 +224,13 @@ struct PredictFn {
             put_once(bT + c, bv);
         }
         // Heun for cs
-        const double css = cs0 + dt * F.cs;
-        const double Fcss = in ? (fcs1 - reaction<REACT>(m, cl0, cd0, css)) : 0.0;
-        const double v = cs0 + (0.5 * dt) * (F.cs + Fcss);
+        double v;
+        {
+#pragma clang fp contract(off)  // (see node_field)
+            const double css = cs0 + dt * F.cs;
+            const double Fcss = in ? (fcs1 - reaction<REACT>(m, cl0, cd0, css)) : 0.0;
+            v = cs0 + (0.5 * dt) * (F.cs + Fcss);
+        }
         put_once(cs1 + c, (REACT != REACT_CS3) ? (in ? v : 0.0 * v) : v);  // RegHCs/HCs: times the interior mask (:3645, :3374)
         // corrector inputs
         const double h = dt / 2;

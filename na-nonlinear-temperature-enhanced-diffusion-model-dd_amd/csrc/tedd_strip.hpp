@@ -1,7 +1,7 @@
 // Register-resident Newton solve for gfx950: the stencil rows and up to H Jacobi sweeps of one
 // 5-diagonal system (2 I - dt J_v) delta = rhs_v in ONE launch, with the iterate kept in VGPRs.
 //
-// A workgroup owns a 64 x 64 tile of nodes.  Lanes map to consecutive columns j; each wave owns a
+// A workgroup owns a tile of 64 columns x W*R rows (see StripShape for the three shapes).  Lanes map to consecutive columns j; each wave owns a
 // strip of R consecutive rows, so a thread holds an R-node column segment: the iterate delta[R] and
 // the scaled matrix row (b, ce, cw, cn, cs)[R] with b = rhs/diag and c* = (dt J_*)/diag.  One sweep
 // delta_c <- b + ce*delta_e + cw*delta_w + cn*delta_n + cs*delta_s  takes the row neighbours
@@ -17,7 +17,7 @@
 // Every node of the tile is updated in every sweep, with zeros standing in for the neighbours
 // outside the tile, so each sweep spoils one more ring of the tile: after s sweeps the nodes at
 // distance >= s from the tile edge hold exactly the s-th global Jacobi iterate (their dependency
-// cone lies inside the tile) and only the (64-2H)^2 interior is written back.  All global loads of the set-up are unconditional (clamped coordinates, results masked) so
+// cone lies inside the tile) and only the interior (H rows / columns in from every edge) is written back.  All global loads of the set-up are unconditional (clamped coordinates, results masked) so
 // that they are issued back to back instead of one dependent round trip per node, and every face
 // coefficient is evaluated once and shared with the neighbouring node (registers for the x faces,
 // a lane shift for the y faces).
@@ -35,15 +35,28 @@
 
 namespace tedd {
 
-constexpr int kSTile = 64;  // tile edge (nodes), halo included
+constexpr int kSTile = 64;  // tile width (nodes = lanes), halo included
 
-template <int VAR>
+// SHAPE_LARGE: 4 waves x 16 rows (64-row tiles): least halo overhead per node; the T system on large
+//   meshes (deep chains of 10 sweeps, lean rows that fit 4 waves per SIMD).
+// SHAPE_MID: 12 waves x 4 rows (48-row tiles): a quarter of the registers per thread, so 6 waves per SIMD
+//   instead of 2 for the full matrix rows of the cl and cd systems (their chains are 4-5 sweeps deep, so
+//   the shorter tile costs little): 4.52 -> 3.74 ms (cl) and 5.39 -> 4.08 ms (cd) at 16384^2.
+// SHAPE_SMALL: 8 waves x 4 rows (32-row tiles): meshes with too few large tiles to occupy the compute
+//   units, where the latency of one tile is the run time (a quarter of the set-up and sweep work per wave,
+//   more and smaller workgroups): 9.6k -> 14.7k steps/s at 256^2.
+// All shapes perform the same arithmetic on every node they write: results do not depend on the shape.
+enum : int { SHAPE_LARGE = 0, SHAPE_SMALL = 1, SHAPE_MID = 2 };
+
+template <int VAR, int SHAPE>
 struct StripShape {
-    static constexpr int R = 16;                        // rows per thread
-    static constexpr int W = kSTile / R;                // waves per workgroup
-    static constexpr int OCC = (VAR == VAR_T) ? 4 : 2;  // waves per SIMD the register budget is set for
-    static constexpr int OCC_LAST = (VAR == VAR_T) ? 4 : 2;  // the launch that also keeps the record
+    static constexpr int R = (SHAPE == SHAPE_LARGE) ? 16 : 4;  // rows per thread
+    static constexpr int W = (SHAPE == SHAPE_LARGE) ? 4 : (SHAPE == SHAPE_MID) ? 12 : 8;  // waves per workgroup
+    static constexpr int TR = R * W;                            // tile height (nodes), halo included
+    // waves per SIMD the register budget is set for
+    static constexpr int OCC = (SHAPE != SHAPE_LARGE) ? 6 : (VAR == VAR_T) ? 4 : 2;
 };
+__host__ __device__ inline int strip_tile_rows(int shape) { return shape == SHAPE_SMALL ? 32 : shape == SHAPE_MID ? 48 : 64; }
 
 // column halo of a launch of depth H: H rounded up to even, so that the row segments a wave reads and
 // the interior it writes stay 16-byte aligned.  (A fixed 8-node halo would keep them on 64-byte lines,
@@ -74,19 +87,19 @@ __device__ __forceinline__ double lane_above(double v) {
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-template <int VAR, int REACT, bool LAST>
-__global__ void __launch_bounds__(64 * StripShape<VAR>::W) __attribute__((amdgpu_waves_per_eu(LAST ? StripShape<VAR>::OCC_LAST : StripShape<VAR>::OCC)))
+template <int VAR, int REACT, bool LAST, int SHAPE>
+__global__ void __launch_bounds__((64 * StripShape<VAR, SHAPE>::W)) __attribute__((amdgpu_waves_per_eu((StripShape<VAR, SHAPE>::OCC))))
 k_solve_strip(const StripArgs A) {
-    constexpr int R = StripShape<VAR>::R, W = StripShape<VAR>::W;
+    constexpr int R = StripShape<VAR, SHAPE>::R, W = StripShape<VAR, SHAPE>::W, TR = StripShape<VAR, SHAPE>::TR;
     constexpr bool LEAN = (VAR == VAR_T);
     __shared__ double seam[2][W][2][kSTile];  // [parity][wave][first/last row of the strip][lane]
-    __shared__ double2 rowc[LEAN ? kSTile : 1];  // lean rows: (dt J_e, dt J_w) of each tile row
+    __shared__ double2 rowc[LEAN ? TR : 1];  // lean rows: (dt J_e, dt J_w) of each tile row
     const int lane = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const GridDev& g = A.g;
     const ModelC& m = A.m;
     const int H = A.H, HC = strip_col_halo(H);
-    const int TIR = kSTile - 2 * H, TIC = kSTile - 2 * HC;
+    const int TIR = TR - 2 * H, TIC = kSTile - 2 * HC;
 
     // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2); give each XCD
     // a contiguous run of tiles so that neighbouring tiles' halos hit the same L2.
@@ -262,7 +275,7 @@ k_solve_strip(const StripArgs A) {
             d[k] = v;
             if (track) {
                 const int r = R * wave + k, li = row0 + k;
-                const bool counted = lane_in && r >= H && r < kSTile - H && li >= A.r0 && li < A.r1 && is_interior(g, li, j);
+                const bool counted = lane_in && r >= H && r < TR - H && li >= A.r0 && li < A.r1 && is_interior(g, li, j);
                 const double up = counted ? fabs(v - cur) : 0.0;
                 up_max = (up > up_max || up != up) ? up : up_max;
             }
@@ -288,7 +301,7 @@ k_solve_strip(const StripArgs A) {
             const double cur = d[k];
             const double prev = (k > 0) ? d[k - 1] : above, nxt = (k < R - 1) ? d[k + 1] : below;
             const double dn = sweep ? update(k, prev, cur, nxt) : cur;  // (all lanes take part in the lane shifts)
-            if (r >= H && r < kSTile - H && li >= A.r0 && li < A.r1 && lane_in) {
+            if (r >= H && r < TR - H && li >= A.r0 && li < A.r1 && lane_in) {
                 const size_t c = at(g, li, jw);
                 if (is_interior(g, li, jw)) {
                     A.u_out[c] = uo[c] + dn;
@@ -305,7 +318,7 @@ k_solve_strip(const StripArgs A) {
         for (int k = 0; k < R; ++k) {
             const int r = R * wave + k;
             const int li = row0w + k;
-            if (r >= H && r < kSTile - H && li >= A.r0 && li < A.r1 && lane_in) {
+            if (r >= H && r < TR - H && li >= A.r0 && li < A.r1 && lane_in) {
                 const size_t c = at(g, li, jw);
                 if (is_interior(g, li, jw)) {
                     A.u_out[c] = uo[c] + d[k];
@@ -322,7 +335,7 @@ k_solve_strip(const StripArgs A) {
         for (int k = 0; k < R; ++k) {
             const int r = R * wave + k;
             const int li = row0w + k;
-            if (r >= H && r < kSTile - H && li >= A.r0 && li < A.r1 && lane_in) A.d_out[at(g, li, jw)] = d[k];
+            if (r >= H && r < TR - H && li >= A.r0 && li < A.r1 && lane_in) A.d_out[at(g, li, jw)] = d[k];
         }
     }
     if (LAST) {
