@@ -832,7 +832,7 @@ public:
         const double t0 = p.t0, dt = p.dt, t1 = p.t0 + p.dt;
         const ForcingSrc f0 = forcing_src(t0, 0), f1 = forcing_src(t1, 1);
         release_retained();
-        be.memset0(d_red, 8 * sizeof(double));
+        be.step_reset(d_red, 8, REACT == REACT_REG ? p.cs_iters : 0);
 
         // cp-forcing cell averages: reuse the array the last step computed for this time level
         const double* fcp_t0 = nullptr;

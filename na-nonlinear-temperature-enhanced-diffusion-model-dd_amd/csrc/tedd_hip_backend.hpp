@@ -122,17 +122,40 @@ __global__ void k_cs_init(unsigned long long* gmax, unsigned long long* gmin, in
         gmin[k] = 0x7FF0000000000000ull;  // +inf
     }
 }
+// start of a predictor-corrector step: the record of the Newton solves (nred doubles) and that of the
+// cs corrector, cleared by one launch
+__global__ void k_step_reset(double* red, int nred, unsigned long long* gmax, unsigned long long* gmin, int iters) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nred) red[k] = 0.0;
+    if (k < iters) {
+        gmax[k] = 0ull;
+        gmin[k] = 0x7FF0000000000000ull;
+    }
+}
+// number of cs Newton iterations the reference keeps: k+1 for the first k with max|dx_k| < rtol min|x_k|
+__device__ __forceinline__ bool cs_stop_after(const unsigned long long* gmax, const unsigned long long* gmin, int k,
+                                              double rtol) {
+    return __longlong_as_double((long long)gmax[k]) < rtol * __longlong_as_double((long long)gmin[k]);
+}
 template <int CASE>
 __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_REG> a, int r0, int r1, int ncols,
                                                   int tiles_x, int ntiles, double* cp_out, double* cs_out, int iters,
-                                                  const int* keep_ptr, unsigned long long* gmax,
+                                                  bool record, double rtol, int* out_keep, unsigned long long* gmax,
                                                   unsigned long long* gmin) {
     extern __shared__ unsigned long long sm[];  // [iters] max bits, [iters] min bits
+    __shared__ int keep_sm;
     const int tid = threadIdx.y * kTileX + threadIdx.x;
-    const bool record = (keep_ptr == nullptr);
     int keep = iters;
     if (!record) {
-        keep = *keep_ptr;          // second pass: only if the global test stopped the iteration early
+        // second pass: every workgroup reads the decision off the record of the first; the iteration is
+        // redone only if the global test stopped it early
+        if (tid == 0) keep_sm = iters;
+        __syncthreads();
+        for (int k = tid; k < iters; k += 256)
+            if (cs_stop_after(gmax, gmin, k, rtol)) atomicMin(&keep_sm, k + 1);
+        __syncthreads();
+        keep = keep_sm;
+        if (blockIdx.x == 0 && tid == 0) out_keep[0] = keep;
         if (keep >= iters) return;
     } else {
         for (int k = tid; k < iters; k += 256) {
@@ -223,9 +246,7 @@ __global__ void k_cs_decide(const unsigned long long* gmax, const unsigned long 
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int keep = iters;
     for (int k = 0; k < iters; ++k) {
-        const double mx = __longlong_as_double((long long)gmax[k]);
-        const double mn = __longlong_as_double((long long)gmin[k]);
-        if (mx < rtol * mn) {
+        if (cs_stop_after(gmax, gmin, k, rtol)) {
             keep = k + 1;
             break;
         }
@@ -260,6 +281,7 @@ struct HipBackend {
     int num_cus = 256;
     double* d_partials = nullptr;
     unsigned long long* d_csstats = nullptr;  // [4096] max, [4096] min
+    int cs_record_clean = 0;                  // leading entries of both known to hold their initial values
     bool profiling = false;
     struct Rec {
         int fam;
@@ -311,6 +333,16 @@ struct HipBackend {
         if (p) (void)hipFree(p);
     }
     void memset0(void* p, size_t bytes) { TEDD_HIP(hipMemsetAsync(p, 0, bytes, stream)); }
+    // clears the record of a step's Newton solves (nred doubles at red) and, for cs_iters > 0, the
+    // record of the cs corrector's Newton iteration
+    void step_reset(double* red, int nred, int cs_iters) {
+        if (cs_iters > 4096) cs_iters = 0;  // (refused later, by correct)
+        const int n = nred > cs_iters ? nred : cs_iters;
+        hipLaunchKernelGGL(k_step_reset, dim3((n + 255) / 256), dim3(256), 0, stream, red, nred, d_csstats,
+                           d_csstats + 4096, cs_iters);
+        TEDD_HIP(hipGetLastError());
+        cs_record_clean = cs_iters;
+    }
     void h2d(void* d, const void* s, size_t bytes) {
         TEDD_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream));
         TEDD_HIP(hipStreamSynchronize(stream));  // the source may be a temporary
@@ -478,13 +510,17 @@ struct HipBackend {
             unsigned long long* gmax = d_csstats;
             unsigned long long* gmin = d_csstats + 4096;
             const size_t lds = (size_t)(iters > 0 ? 2 * iters : 2) * sizeof(unsigned long long);
-            if (iters > 0) hipLaunchKernelGGL(k_cs_init, dim3((iters + 255) / 256), dim3(256), 0, stream, gmax, gmin, iters);
+            if (iters > 4096) throw std::runtime_error("more than 4096 cs Newton iterations");
+            if (iters > 0 && cs_record_clean < iters)
+                hipLaunchKernelGGL(k_cs_init, dim3((iters + 255) / 256), dim3(256), 0, stream, gmax, gmin, iters);
+            cs_record_clean = 0;
             hipLaunchKernelGGL(k_cs_newton<CASE>, dim3(nb), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx, nt,
-                               cp_out, cs_out, iters, (const int*)nullptr, gmax, gmin);
-            hipLaunchKernelGGL(k_cs_decide, dim3(1), dim3(1), 0, stream, gmax, gmin, iters, rtol, d_keep);
-            if (iters > 1)
+                               cp_out, cs_out, iters, true, rtol, d_keep, gmax, gmin);
+            if (iters > 1)  // decides by itself whether anything is left to do
                 hipLaunchKernelGGL(k_cs_newton<CASE>, dim3(nb), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx,
-                                   nt, cp_out, cs_out, iters, (const int*)d_keep, gmax, gmin);
+                                   nt, cp_out, cs_out, iters, false, rtol, d_keep, gmax, gmin);
+            else
+                hipLaunchKernelGGL(k_cs_decide, dim3(1), dim3(1), 0, stream, gmax, gmin, iters, rtol, d_keep);
             TEDD_HIP(hipGetLastError());
         }
     }

@@ -23,6 +23,7 @@ struct CpuBackend {
     void* alloc(size_t bytes) { return std::calloc(bytes ? bytes : 1, 1); }
     void free(void* p) { std::free(p); }
     void memset0(void* p, size_t bytes) { std::memset(p, 0, bytes); }
+    void step_reset(double* red, int nred, int) { std::memset(red, 0, nred * sizeof(double)); }
     void h2d(void* d, const void* s, size_t b) { std::memcpy(d, s, b); }
     void d2h(void* d, const void* s, size_t b) { std::memcpy(d, s, b); }
     void h2d_2d(double* d, size_t dp, const double* s, size_t sp, int w, int rows) {
