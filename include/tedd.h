@@ -42,7 +42,8 @@ enum tedd_mms_case {
     TEDD_MMS_POL = 0,     /* src/prob1_mms_cases.py:250-277 */
     TEDD_MMS_EXPSIN = 1,  /* src/prob1_mms_cases.py:280-337 */
     TEDD_MMS_PEAKS = 2,   /* src/prob1_mms_cases.py:151-247; params [leading_spatial_const, evol_speed] */
-    TEDD_MMS_NFS = 3      /* src/prob1_mms_cases.py:406-511; params [gamma_cp,gamma_T,gamma_cl,gamma_cd,gamma_cs,theta] */
+    TEDD_MMS_NFS = 3,     /* src/prob1_mms_cases.py:406-511; params [gamma_cp,gamma_T,gamma_cl,gamma_cd,gamma_cs,theta] */
+    TEDD_MMS_PROGRAM = 4  /* any exact solution, as expression programs set with tedd_set_mms_program */
 };
 
 enum tedd_reaction {
@@ -79,6 +80,20 @@ const char* tedd_last_error(const tedd_ctx* ctx); /* ctx may be NULL: error of t
  * place between steps, e.g. tests/test_time_integrator_hcs_triple.py:377-387). */
 int tedd_set_model(tedd_ctx* ctx, const double consts[17], int32_t model_kind, double eta,
                    const double mms_params[8]);
+/* The exact solution of a TEDD_MMS_PROGRAM context.  Replaces MMSCaseSymbolic's lambdified SymPy
+ * expressions (src/prob1base.py:1225-1347): the caller lowers the expressions of (t, x, y) to straight-line
+ * programs of three-address operations on at most 96 double registers (registers 0, 1, 2 hold t, x, y on
+ * entry), which every node then runs on the device.  which 0: the node program, 21 outputs
+ *   cp cp_t cp_x cp_y | T T_t T_x T_y lap_T | cl cl_t cl_x cl_y lap_cl | cd cd_t cd_x cd_y lap_cd | cs cs_t;
+ * which 1: the cell program, 4 outputs cp cp_t cl T, run at the 3 x 3 Gauss points of a node's cell for the
+ * cell-averaged cp-forcing (src/prob1base.py:493-598, 2313-2328).  Both must be set before the first call that
+ * needs the exact solution or the forcing.  Word: op | dst << 8 | a << 16 | b << 24 with op
+ *   0 CONST dst = consts[a | b << 8]   1 ADD  2 SUB  3 MUL  4 DIV  5 NEG   6 POWI dst = reg[a] ** (int8) b
+ *   7 POW  8 EXP  9 SIN  10 COS  11 SQRT  12 LOG  13 ABS  14 SIGN  15 TANH  16 OUT out[dst] = reg[a]  17 MOV.
+ * Every word is validated (register, constant and output indices, use before definition, all outputs
+ * written); a malformed program is TEDD_ERR_INVALID. */
+int tedd_set_mms_program(tedd_ctx* ctx, int32_t which, const uint32_t* code, int32_t n_ops, const double* consts,
+                         int32_t n_consts, int32_t n_regs);
 /* Execution options (no counterpart in the reference; they select between implementations that give
  * the same results).  "strip_solve" (default 1): solve the Newton systems with the register-resident
  * kernel chain (several Jacobi sweeps per launch) instead of one launch per sweep; "strip_hmax": sweeps

@@ -85,6 +85,10 @@ int tedd_set_model(tedd_ctx* ctx, const double consts[17], int32_t model_kind, d
         C.set_model(consts, model_kind, eta, mms_params);
     });
 }
+int tedd_set_mms_program(tedd_ctx* ctx, int32_t which, const uint32_t* code, int32_t n_ops, const double* consts,
+                         int32_t n_consts, int32_t n_regs) {
+    return guarded(ctx, [&](auto& C) { C.set_mms_program(which, code, n_ops, consts, n_consts, n_regs); });
+}
 int tedd_set_option(tedd_ctx* ctx, const char* name, double value) {
     return guarded(ctx, [&](auto& C) {
         if (!name) throw tedd::InvalidError("name is null");

@@ -19,6 +19,7 @@
 #include "../../include/tedd.h"
 #include "tedd_mms_host.hpp"
 #include "tedd_nodes.hpp"
+#include "tedd_prog.hpp"
 
 namespace tedd {
 
@@ -104,9 +105,18 @@ public:
     // then runs closer to the HBM roofline).  -1: fuse up to 4 M nodes per slab.
     int opt_fuse_forcing = -1;
     bool fuse_forcing_now() const {
+        if (mms_case == CASE_PROG) return false;
         return opt_fuse_forcing < 0 ? (size_t)nrows * ncols <= ((size_t)1 << 22) : opt_fuse_forcing != 0;
     }
     bool predict_makes_f1 = false;
+    // CASE_PROG: the exact solution as expression programs (tedd_prog.hpp).  [0] node program, [1] cell program
+    struct ProgStore {
+        uint32_t* d_code = nullptr;
+        double* d_consts = nullptr;
+        int n_ops = 0, n_regs = 0;
+    } prog[2];
+    double *d_px = nullptr, *d_py = nullptr, *d_pxq = nullptr, *d_pyq = nullptr;
+    int prog_k0 = 0;  // forcing set serving time level 0 of the current call
     int fset[2] = {0, 1};            // which physical array set serves time level 0 / 1
     double fset_time[2] = {NAN, NAN};
     bool forcing_from_cache = false;
@@ -119,7 +129,7 @@ public:
         if (c.ghost < 0) throw InvalidError("ghost < 0");
         if (c.model_kind != 1 && c.model_kind != 2) throw InvalidError("model_kind must be 1 or 2");
         if (c.reaction_kind != REACT_CS3 && c.reaction_kind != REACT_REG && c.reaction_kind != REACT_HCS) throw InvalidError("bad reaction_kind");
-        if (c.mms_case < CASE_STREAM || c.mms_case > CASE_NFS) throw InvalidError("bad mms_case");
+        if (c.mms_case < CASE_STREAM || c.mms_case > CASE_PROG) throw InvalidError("bad mms_case");
         xg.assign(x, x + N + 1);
         yg.assign(y, y + M + 1);
         for (int i = 1; i <= N; ++i)
@@ -154,6 +164,14 @@ public:
         be.free(d_by);
         be.free(d_bxq);
         be.free(d_byq);
+        for (ProgStore& q : prog) {
+            be.free(q.d_code);
+            be.free(q.d_consts);
+        }
+        be.free(d_px);
+        be.free(d_py);
+        be.free(d_pxq);
+        be.free(d_pyq);
         be.free(d_red);
         be.free(d_series);
         be.free(d_ints);
@@ -258,7 +276,7 @@ public:
         be.free(d_bxq);
         be.free(d_byq);
         d_bx = d_by = d_bxq = d_byq = nullptr;
-        if (mms_case == CASE_STREAM) return;
+        if (mms_case == CASE_STREAM || mms_case == CASE_PROG) return;
         std::vector<double> nx, qx, ny, qy;
         build_axis_tables(mms_case, mp, xg, i0, nrows, nrows, nx, qx);
         build_axis_tables(mms_case, mp, yg, 0, ncols, ld, ny, qy);
@@ -273,12 +291,123 @@ public:
         d_byq = up(qy);
     }
     MmsTabs tabs() const { return MmsTabs{d_bx, d_by, d_bxq, d_byq, nrows, ld}; }
+
+    // ---- expression programs (CASE_PROG)
+    // Every word is checked here, once, so that the interpreter can index registers, constants and
+    // outputs without bounds checks.
+    void set_mms_program(int which, const uint32_t* code, int n_ops, const double* consts, int n_consts, int n_regs) {
+        if (mms_case != CASE_PROG) throw InvalidError("context was not created for an MMS program");
+        if (which != 0 && which != 1) throw InvalidError("which must be 0 (node program) or 1 (cell program)");
+        if (!code || n_ops < 1 || n_ops > (1 << 20)) throw InvalidError("bad program length");
+        if (n_consts < 0 || n_consts > 65536 || (n_consts > 0 && !consts)) throw InvalidError("bad constant table");
+        if (n_regs < 3 || n_regs > kProgMaxRegs) throw InvalidError("register count must be in [3, 96]");
+        const int n_out = which == 0 ? kProgNodeOutputs : kProgCellOutputs;
+        std::vector<char> written(n_out, 0), defined(n_regs, 0);
+        defined[0] = defined[1] = defined[2] = 1;
+        for (int pc = 0; pc < n_ops; ++pc) {
+            const uint32_t w = code[pc];
+            const int op = (int)(w & 0xffu), d = (int)((w >> 8) & 0xffu), a = (int)((w >> 16) & 0xffu), b = (int)(w >> 24);
+            if (op < 0 || op >= POP_COUNT) throw InvalidError("program: unknown operation");
+            if (op == POP_CONST) {
+                if ((a | (b << 8)) >= n_consts || d >= n_regs) throw InvalidError("program: constant or register out of range");
+                defined[d] = 1;
+                continue;
+            }
+            if (a >= n_regs || !defined[a]) throw InvalidError("program: operand register undefined or out of range");
+            if (op == POP_OUT) {
+                if (d >= n_out) throw InvalidError("program: output slot out of range");
+                written[d] = 1;
+                continue;
+            }
+            const bool binary = (op == POP_ADD || op == POP_SUB || op == POP_MUL || op == POP_DIV || op == POP_POW);
+            if (binary && (b >= n_regs || !defined[b])) throw InvalidError("program: operand register undefined or out of range");
+            if (d >= n_regs) throw InvalidError("program: destination register out of range");
+            defined[d] = 1;
+        }
+        for (char wv : written)
+            if (!wv) throw InvalidError("program: an output is never written");
+        ProgStore& q = prog[which];
+        be.free(q.d_code);
+        be.free(q.d_consts);
+        q.d_code = (uint32_t*)be.alloc((size_t)n_ops * sizeof(uint32_t));
+        q.d_consts = (double*)be.alloc((size_t)std::max(n_consts, 1) * sizeof(double));
+        be.h2d(q.d_code, code, (size_t)n_ops * sizeof(uint32_t));
+        if (n_consts > 0) be.h2d(q.d_consts, consts, (size_t)n_consts * sizeof(double));
+        q.n_ops = n_ops;
+        q.n_regs = n_regs;
+        fset_time[0] = fset_time[1] = NAN;
+        if (!d_px) build_prog_axes();
+    }
+    void build_prog_axes() {
+        // node coordinates and the 3 Gauss-Legendre points of each interior node's cell
+        // [x_{i-1/2}, x_{i+1/2}] (src/prob1base.py:493-598), per axis
+        const double gl[3] = {-std::sqrt(3.0 / 5.0), 0.0, std::sqrt(3.0 / 5.0)};
+        auto axis = [&](const std::vector<double>& co, int first, int count, int stride, std::vector<double>& nodal,
+                        std::vector<double>& quad) {
+            const int n = (int)co.size() - 1;
+            nodal.assign(stride, 0.0);
+            quad.assign((size_t)3 * stride, 0.0);
+            for (int l = 0; l < count; ++l) {
+                const int i = first + l;
+                if (i < 0 || i > n) continue;
+                nodal[l] = co[i];
+                if (i >= 1 && i <= n - 1) {
+                    const double base = 0.5 * (co[i - 1] + co[i]);
+                    const double width = 0.5 * ((co[i] - co[i - 1]) + (co[i + 1] - co[i]));
+                    for (int a = 0; a < 3; ++a) quad[(size_t)a * stride + l] = base + (gl[a] + 1.0) * 0.5 * width;
+                }
+            }
+        };
+        std::vector<double> nx, qx, ny, qy;
+        axis(xg, i0, nrows, nrows, nx, qx);
+        axis(yg, 0, ncols, ld, ny, qy);
+        auto up = [&](const std::vector<double>& v) {
+            double* d = (double*)be.alloc(v.size() * sizeof(double));
+            be.h2d(d, v.data(), v.size() * sizeof(double));
+            return d;
+        };
+        d_px = up(nx);
+        d_py = up(ny);
+        d_pxq = up(qx);
+        d_pyq = up(qy);
+    }
+    MmsProg program(int which) const {
+        if (!prog[which].d_code) throw InvalidError("the MMS programs have not been set (tedd_set_mms_program)");
+        return MmsProg{prog[which].d_code, prog[which].d_consts, prog[which].n_ops};
+    }
+    ProgAxes prog_axes() const { return ProgAxes{d_px, d_py, d_pxq, d_pyq, nrows, ld}; }
+    void prog_exact(double t, double* const out[5], int what) {
+        Out5 o;
+        for (int v = 0; v < 5; ++v) o.v[v] = out[v];
+        ProgExactFn f{grid(), program(0), prog_axes(), t, o, what};
+        be.nodes_prog(FAM_MISC, f, 0, nrows, ncols, prog[0].n_regs);
+        for (int v = 0; v < 5; ++v) mark(out[v], full());
+    }
+    template <int REACT>
+    void prog_forcing(double t, double* const out[5]) {
+        Out5 o;
+        for (int v = 0; v < 5; ++v) o.v[v] = out[v];
+        ProgForcingFn<REACT> f{grid(), model, program(0), program(1), prog_axes(), t, o};
+        be.nodes_prog(FAM_FORCING, f, 0, nrows, ncols, std::max(prog[0].n_regs, prog[1].n_regs));
+    }
+
     ForcingSrc forcing_src(double t, int which) {
         ForcingSrc s;
         s.tm = mms_time_fill(mms_case, model, mp, t);
         for (int v = 0; v < 5; ++v) s.f[v] = nullptr;
         if (forcing_from_cache) {
             for (int v = 0; v < 5; ++v) s.f[v] = slot[(fset[which] ? SF10 : SF00) + v];
+        } else if (mms_case == CASE_PROG) {
+            // the array-fed kernels read the set of this time level, evaluated by the programs on first use
+            int k = -1;
+            for (int q = 0; q < 2; ++q)
+                if (fset_time[q] == t) k = q;
+            if (k < 0) {
+                k = (which == 0) ? 0 : 1 - prog_k0;  // (keep the set time level 0 of this call reads)
+                fill_forcing_set(t, k);
+            }
+            if (which == 0) prog_k0 = k;
+            for (int v = 0; v < 5; ++v) s.f[v] = slot[(k ? SF10 : SF00) + v];
         } else if (mms_case == CASE_STREAM) {
             if (!stream_forcing_set[which]) throw InvalidError("streamed forcing not set for this time level");
             for (int v = 0; v < 5; ++v) s.f[v] = slot[(which ? SF10 : SF00) + v];
@@ -404,7 +533,11 @@ public:
     // ------------------------------------------------------------------ dispatch helpers
     template <class Fn>
     void dispatch(Fn&& fn, int case_override = -100) {
-        const int c = (case_override == -100) ? mms_case : case_override, r = react;
+        // (a program case runs the array-fed kernels; the operations that evaluate the exact solution
+        // or the forcing check mms_case themselves)
+        int c = (case_override == -100) ? mms_case : case_override;
+        if (c == CASE_PROG) c = CASE_STREAM;
+        const int r = react;
 #define TEDD_D(CC, RR)             \
     if (c == CC && r == RR) {      \
         fn.template run<CC, RR>(); \
@@ -497,6 +630,10 @@ public:
         template <int CASE, int REACT>
         void run() {
             Ctx& C = *c;
+            if (C.mms_case == CASE_PROG) {
+                C.prog_exact(t, out, what);
+                return;
+            }
             if (CASE == CASE_STREAM) throw InvalidError("no closed-form exact solution for streamed forcing");
             Out5 o;
             for (int v = 0; v < 5; ++v) o.v[v] = out[v];
@@ -528,6 +665,10 @@ public:
         template <int CASE, int REACT>
         void run() {
             Ctx& C = *c;
+            if (C.mms_case == CASE_PROG) {
+                C.template prog_forcing<REACT>(t, out);
+                return;
+            }
             if (CASE == CASE_STREAM) throw InvalidError("forcing is streamed: nothing to evaluate");
             Out5 o;
             for (int v = 0; v < 5; ++v) o.v[v] = out[v];
@@ -582,6 +723,11 @@ public:
         template <int CASE, int REACT>
         void run() {
             Ctx& C = *c;
+            if (C.mms_case == CASE_PROG) {  // exact fields from the program, then the array-fed norms
+                double* ex[5];
+                for (int v = 0; v < 5; ++v) ex[v] = C.B(EX0 + v);
+                C.prog_exact(t, ex, 0);
+            }
             ErrNormFn<CASE> f;
             f.g = C.grid();
             f.m = C.model;
@@ -652,7 +798,7 @@ public:
             p.sweeps[v] = (s > 0) ? std::max(2, (int)s) : auto_sweeps(dt * std::fabs(dcoef[v]) * q_metric, jtol, jmax);
         }
         PcOp op{this, p};
-        if (opt_cache_forcing && mms_case != CASE_STREAM) {
+        if ((opt_cache_forcing || mms_case == CASE_PROG) && mms_case != CASE_STREAM) {
             // evaluate the closed-form forcing once per time level, then run the array-fed kernels
             int k0 = -1;
             for (int k = 0; k < 2; ++k)
@@ -1127,8 +1273,12 @@ public:
             Ctx& C = *c;
             const GridDev g = C.grid();
             ForcingSrc f1;
-            f1.tm = mms_time_fill(C.mms_case, C.model, C.mp, C.last.t1);
-            for (int v = 0; v < 5; ++v) f1.f[v] = (CASE == CASE_STREAM) ? C.slot[SF10 + v] : nullptr;
+            if (C.mms_case == CASE_PROG) {
+                f1 = C.forcing_src(C.last.t1, 1);
+            } else {
+                f1.tm = mms_time_fill(C.mms_case, C.model, C.mp, C.last.t1);
+                for (int v = 0; v < 5; ++v) f1.f[v] = (CASE == CASE_STREAM) ? C.slot[SF10 + v] : nullptr;
+            }
             const double *cp = C.last.cp_used, *cs = C.last.cs_used;
             const double *T1 = C.cur[VAR_T], *cl1 = C.cur[VAR_CL], *cd1 = C.cur[VAR_CD];
             const double *YT = C.slot[Y0], *Ycl = C.slot[Y0 + 1], *Ycd = C.slot[Y0 + 2];

@@ -31,6 +31,16 @@ __global__ void __launch_bounds__(256) k_nodes(const F f, int r0, int r1, int nc
     if (j < ncols && li < r1) f(li, j);
 }
 
+// Node functors that interpret an expression program (tedd_prog.hpp): one wave per workgroup, the
+// program's registers in LDS as [register][lane].
+template <class F>
+__global__ void __launch_bounds__(64) k_nodes_prog(const F f, int r0, int r1, int ncols) {
+    extern __shared__ double prog_regs[];
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int li = r0 + blockIdx.y;
+    if (j < ncols && li < r1) f(li, j, prog_regs + threadIdx.x, 64);
+}
+
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -422,6 +432,17 @@ struct HipBackend {
         Scope sc(this, fam);
         dim3 block(kTileX, kTileY), grid((ncols + kTileX - 1) / kTileX, (r1 - r0 + kTileY - 1) / kTileY);
         hipLaunchKernelGGL(k_nodes<F>, grid, block, 0, stream, f, r0, r1, ncols);
+        TEDD_HIP(hipGetLastError());
+    }
+    template <class F>
+    void nodes_prog(int fam, const F& f, int r0, int r1, int ncols, int n_regs) {
+        check_range(r0, r1, ncols);
+        if (r1 == r0) return;
+        if (n_regs < 3 || n_regs > kProgMaxRegs) throw std::runtime_error("bad program register count");
+        if (r1 - r0 > 65535) throw std::runtime_error("slab too tall for the program launch");
+        Scope sc(this, fam);
+        dim3 block(64, 1), grid((ncols + 63) / 64, r1 - r0);
+        hipLaunchKernelGGL(k_nodes_prog<F>, grid, block, (size_t)n_regs * 64 * sizeof(double), stream, f, r0, r1, ncols);
         TEDD_HIP(hipGetLastError());
     }
     static void tiling(int r0, int r1, int ncols, int& tiles_x, int& ntiles, int& nblocks) {

@@ -22,7 +22,9 @@
 
 namespace tedd {
 
-enum : int { CASE_STREAM = -1, CASE_POL = 0, CASE_EXPSIN = 1, CASE_PEAKS = 2, CASE_NFS = 3 };
+// CASE_PROG is a run-time case (expression programs, tedd_prog.hpp); the kernels templated on a case
+// never see it: its forcing reaches them as arrays (CASE_STREAM).
+enum : int { CASE_STREAM = -1, CASE_POL = 0, CASE_EXPSIN = 1, CASE_PEAKS = 2, CASE_NFS = 3, CASE_PROG = 4 };
 enum : int { REACT_CS3 = 0, REACT_REG = 1, REACT_HCS = 2 };
 enum : int { VAR_CP = 0, VAR_T = 1, VAR_CL = 2, VAR_CD = 3, VAR_CS = 4 };
 

@@ -17,7 +17,7 @@ DEFAULT_LIBRARY = os.path.join(_PKG_ROOT, "lib", "libtedd_hip.so")
 CONST_NAMES = ("R0", "Ea", "K1", "K2", "K3", "K4", "DT", "Dl_max", "phi_l", "gamma_T",
                "Kd", "Sd", "Dd_max", "phi_d", "phi_T", "r_sp", "T_ref")
 
-MMS_STREAM, MMS_POL, MMS_EXPSIN, MMS_PEAKS, MMS_NFS = -1, 0, 1, 2, 3
+MMS_STREAM, MMS_POL, MMS_EXPSIN, MMS_PEAKS, MMS_NFS, MMS_PROGRAM = -1, 0, 1, 2, 3, 4
 REACT_CSTRIPLE, REACT_REGHCSTRIPLE, REACT_HCSTRIPLE = 0, 1, 2
 
 _dptr = C.POINTER(C.c_double)
@@ -51,6 +51,7 @@ PROTOTYPES = {
     "tedd_last_error": (C.c_char_p, [C.c_void_p]),
     "tedd_set_model": (C.c_int, [C.c_void_p, _dptr, C.c_int32, C.c_double, _dptr]),
     "tedd_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "tedd_set_mms_program": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
     "tedd_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tedd_sync": (C.c_int, [C.c_void_p]),
     "tedd_local_rows": (C.c_int32, [C.c_void_p]),
@@ -201,6 +202,14 @@ class Context:
         params = list(mms_params) + [0.0] * (8 - len(mms_params))
         p = (C.c_double * 8)(*[float(v) for v in params])
         self._check(self._lib.tedd_set_model(self._h, c, model_kind, float(eta), p))
+
+    def set_mms_program(self, which, code, consts, n_regs):
+        """code: uint32 words, consts: float64 (tedd_set_mms_program; which 0 node program, 1 cell program)."""
+        code = np.ascontiguousarray(code, dtype=np.uint32)
+        consts = np.ascontiguousarray(consts, dtype=np.float64)
+        self._check(self._lib.tedd_set_mms_program(
+            self._h, int(which), code.ctypes.data, int(code.size),
+            consts.ctypes.data if consts.size else None, int(consts.size), int(n_regs)))
 
     def set_option(self, name, value):
         self._check(self._lib.tedd_set_option(self._h, name.encode(), float(value)))

@@ -7,8 +7,8 @@ arguments.
 The classes derived from MMSCaseDevice only record which closed form of the device library to use and
 its parameters; the values (exact solution, its derivatives, and the forcing terms derived from them)
 are computed on the GPU.  The classes derived from MMSCaseSymbolic (StiffExpDecay,
-PolWithOscilatingTime, CsZeroCrossing) state their solution as SymPy expressions; their forcing terms
-are evaluated on the host and streamed to the device at every time level.
+PolWithOscilatingTime, CsZeroCrossing) state their solution as SymPy expressions, which are lowered to
+register programs that the device library runs at every node (tedd/_symprog.py).
 """
 from __future__ import annotations
 

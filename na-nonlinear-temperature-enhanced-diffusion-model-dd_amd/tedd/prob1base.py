@@ -25,6 +25,7 @@ from typing import Callable, Dict, List, NamedTuple
 import numpy as np
 
 from . import _ffi
+from . import _symprog
 
 Diag5 = namedtuple("Diag5", ["sub", "rspec", "cspec"])
 
@@ -404,13 +405,17 @@ class _Session:
     """One C-ABI context for a (grid, reaction kind, forcing source) combination, with the model
     constants re-sent whenever they changed since the last call."""
 
-    def __init__(self, grid: Grid, model, react, eta, mms_case, mms_params):
+    def __init__(self, grid: Grid, model, react, eta, mms_case, mms_params, program=None):
         self.grid = grid
         self.react = react
         self.mms_case = mms_case
         self._sent = None
         self.ctx = _ffi.Context(grid.x, grid.y, model.consts_vector(), model_kind=model.model_kind,
                                 reaction_kind=react, eta=eta, mms_case=mms_case, mms_params=mms_params)
+        if mms_case == _ffi.MMS_PROGRAM:
+            node, cell = program
+            self.ctx.set_mms_program(0, *node)
+            self.ctx.set_mms_program(1, *cell)
         self._sent = self._key(model, eta, mms_params)
         self.state_token = None   # identity of the StateVars the device state equals
 
@@ -600,12 +605,20 @@ def _lambdify_txy(expr, t_var, x_var, y_var):
 
 class MMSCaseSymbolic(MMSCaseBase):
     """Exact solution given as SymPy expressions of (t, x, y); the derivatives the forcing terms need
-    are derived symbolically and lambdified for NumPy (reference src/prob1base.py:1225-1347).  The
-    library has no closed form for such a case: its forcing terms are evaluated on the host and their
-    arrays streamed to the device at every time level."""
+    are derived symbolically (reference src/prob1base.py:1225-1347).  The accessors cp, dt_cp, ... are
+    lambdified for NumPy as in the reference.  For the device the same expressions are lowered to
+    register programs (tedd/_symprog.py) that the library runs at every node, so forcing terms, exact
+    solution and error norms of such a case never leave the GPU; if an expression uses something the
+    program operations do not cover (or device_program=False), the forcing terms are evaluated on the
+    host instead and their arrays streamed to the device at every time level."""
+
+    mms_case_id = _ffi.MMS_PROGRAM
+
+    def mms_params(self):
+        return ()
 
     def __init__(self, *, grid: Grid, model: DefaultModel01, cp_sym_expr, T_sym_expr, cl_sym_expr, cd_sym_expr,
-                 cs_sym_expr, t_var=None, x_var=None, y_var=None):
+                 cs_sym_expr, t_var=None, x_var=None, y_var=None, device_program=True):
         if _sympy is None:
             raise ImportError("MMSCaseSymbolic needs sympy")
         super().__init__(grid, model)
@@ -613,13 +626,21 @@ class MMSCaseSymbolic(MMSCaseBase):
         x_var = x_sym if x_var is None else x_var
         y_var = y_sym if y_var is None else y_var
         exprs = {"cp": cp_sym_expr, "T": T_sym_expr, "cl": cl_sym_expr, "cd": cd_sym_expr, "cs": cs_sym_expr}
+        named = {}
         for var, expr in exprs.items():
             expr = _sympy.sympify(expr)
             dx, dy = _sympy.diff(expr, x_var), _sympy.diff(expr, y_var)
             pack = {"": expr, "dt_": _sympy.diff(expr, t_var), "dx_": dx, "dy_": dy,
                     "lap_": _sympy.diff(dx, x_var) + _sympy.diff(dy, y_var)}
             for prefix, e in pack.items():
+                named[prefix + var] = e
                 setattr(self, prefix + var, _lambdify_txy(e, t_var, x_var, y_var))
+        self._program = None
+        if device_program:
+            try:
+                self._program = _symprog.lower_case(named, t_var, x_var, y_var)
+            except _symprog.Unsupported:
+                self._program = None
 
 
 def avg_int(f: Callable, grid: Grid):
@@ -705,8 +726,8 @@ class _DeviceForcingTerms(ForcingTermsBase):
 
     def __init__(self, *, mms_case: MMSCaseBase, model: DefaultModel01, eta=0.0):
         # a case the library has no closed form for: evaluate on the host, the field streams the arrays
-        self._host = None if isinstance(mms_case, MMSCaseDevice) else _HostForcingTerms(
-            mms_case, model, self.reaction_kind, eta)
+        on_device = isinstance(mms_case, MMSCaseDevice) or getattr(mms_case, "_program", None) is not None
+        self._host = None if on_device else _HostForcingTerms(mms_case, model, self.reaction_kind, eta)
         self._mms_case = mms_case
         self._model = model
         self._eta = float(eta)
@@ -742,7 +763,8 @@ class _DeviceForcingTerms(ForcingTermsBase):
             raise NotImplementedError("device forcing terms are evaluated at the nodes of their own grid")
         if self._session is None:
             self._session = _Session(self.grid, self._model, self.reaction_kind, self._eta,
-                                     self._mms_case.mms_case_id, self._mms_case.mms_params())
+                                     self._mms_case.mms_case_id, self._mms_case.mms_params(),
+                                     program=getattr(self._mms_case, "_program", None))
         self._session.refresh(self._model, self._eta, self._mms_case.mms_params())
         key = (float(t), self._session._sent)
         if key not in self._memo:
@@ -876,13 +898,13 @@ class _DeviceField(SemiDiscreteFieldBase):
         if src is not None:
             case = src.mms_case
             key = ("mms", case.mms_case_id, id(case))
-            mms_id, params = case.mms_case_id, case.mms_params()
+            mms_id, params, program = case.mms_case_id, case.mms_params(), getattr(case, "_program", None)
         else:
             key = ("stream",)
-            mms_id, params = _ffi.MMS_STREAM, ()
+            mms_id, params, program = _ffi.MMS_STREAM, (), None
         s = self._sessions.get(key)
         if s is None:
-            s = _Session(self._grid, self._model, self.reaction_kind, self._eta_now(), mms_id, params)
+            s = _Session(self._grid, self._model, self.reaction_kind, self._eta_now(), mms_id, params, program=program)
             self._sessions = {key: s}
         s.refresh(self._model, self._eta_now(), params)
         return s

@@ -375,16 +375,19 @@ def check_integrator_pieces(kind):
         integ.corrector_cp_step(T1, cl1, cd1, at_t0=S0, t0=t0, dt=0.0)
 
 
-def check_symbolic_case_equals_builtin(kind):
+def check_symbolic_case_equals_builtin(kind, device_program=True):
     """An MMSCaseSymbolic with the expressions of MMSCasePol (u = x(1-x) y(1-y) / (1+t) for all five,
-    reference src/prob1_mms_cases.py:151-186): its host-evaluated, streamed forcing terms and the steps
-    taken with them agree with the library's closed-form Pol case."""
+    reference src/prob1_mms_cases.py:151-186): its forcing terms -- evaluated on the device by the lowered
+    expression programs, or on the host and streamed (device_program=False) -- and the steps taken with
+    them agree with the library's closed-form Pol case; so do the device-resident run with error norms
+    and the exact solution."""
     sympy = pytest.importorskip("sympy")
     model = model_of("nb_b")
     grid = p1.Grid(np.linspace(0, 1, 9) ** 1.2, np.linspace(0, 1, 7))
     u = p1.x_sym * (1 - p1.x_sym) * p1.y_sym * (1 - p1.y_sym) / (1 + p1.t_sym)
     sym = p1.MMSCaseSymbolic(grid=grid, model=model, cp_sym_expr=u, T_sym_expr=u, cl_sym_expr=u, cd_sym_expr=u,
-                             cs_sym_expr=u)
+                             cs_sym_expr=u, device_program=device_program)
+    assert (sym._program is not None) == device_program
     pol = p1mc.MMSCasePol(grid=grid, model=model)
     classes = {"reg": (p1.ForcingTerms_RegHCsTriple, p1.SemiDiscreteField_RegHCsTriple,
                        p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple, {"regularization_factor": ETA}),
@@ -400,7 +403,7 @@ def check_symbolic_case_equals_builtin(kind):
                                        rtol=0, atol=1e-13, err_msg=f"{name} t={t}")
     field_a = Fld(grid=grid, model=model, forcing_terms=fa, **common)
     field_b = Fld(grid=grid, model=model, forcing_terms=fb, **common)
-    assert field_a._closed_form_source() is None and field_b._closed_form_source() is fb
+    assert field_a._closed_form_source() is (fa if device_program else None) and field_b._closed_form_source() is fb
     ia, ib = Integ(field_a, **common), Integ(field_b, **common)
     Sa = p1.state_from_mms_when(mms_case=sym, t=0.0, grid=grid)
     Sb = p1.state_from_mms_when(mms_case=pol, t=0.0, grid=grid)
@@ -410,6 +413,25 @@ def check_symbolic_case_equals_builtin(kind):
         t += dt
     for v in ("cp", "T", "cl", "cd", "cs"):
         np.testing.assert_allclose(getattr(Sa, v), getattr(Sb, v), rtol=0, atol=1e-14, err_msg=v)
+    for v in ("T", "cl", "cd"):
+        np.testing.assert_allclose(ia.last_residual[v], ib.last_residual[v], rtol=0, atol=1e-14, err_msg="res " + v)
+    if not device_program:
+        with pytest.raises(NotImplementedError):
+            ia.advance_with_errors(Sa, t0=t, dt=dt, num_steps=2)
+        return
+    # device-resident run with the fused error norms, and the field evaluation
+    S0a = p1.state_from_mms_when(mms_case=sym, t=0.0, grid=grid)
+    S0b = p1.state_from_mms_when(mms_case=pol, t=0.0, grid=grid)
+    (Fa, ea), (Fb, eb) = (ia.advance_with_errors(S0a, t0=0.0, dt=dt, num_steps=4),
+                          ib.advance_with_errors(S0b, t0=0.0, dt=dt, num_steps=4))
+    np.testing.assert_allclose(ea, eb, rtol=1e-9, atol=1e-26)
+    for v in ("cp", "T", "cl", "cd", "cs"):
+        np.testing.assert_allclose(getattr(Fa, v), getattr(Fb, v), rtol=0, atol=1e-14, err_msg=v)
+    np.testing.assert_allclose(field_a.Fcl(S0a, 0.1), field_b.Fcl(S0b, 0.1), rtol=0, atol=1e-13)
+    s = field_a._device()
+    for what in range(5):
+        for a, b in zip(s.ctx.eval_mms(0.37, what), pol._eval(what, 0.37, None, None)):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-13, equal_nan=True)
 
 
 def check_symbolic_cs_ramp(cs_initial, cs_slope, dt=0.01):

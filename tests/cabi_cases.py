@@ -3,6 +3,7 @@ library (the HIP library on a GPU box, or the host twin on CPU) and return error
 import os
 
 import numpy as np
+import pytest
 
 from tedd import _ffi
 
@@ -217,6 +218,78 @@ def check_hcs_denominator_error():
         raise AssertionError("no ValueError")
     ctx.get_stats()  # the condition is reported once
     ctx.close()
+
+
+# ---------------------------------------------------------------------------------- expression programs
+def check_mms_program(react):
+    """TEDD_MMS_PROGRAM through the C ABI: the exact solution, its derivatives, the five forcing arrays
+    and a few steps from programs lowered from the expressions of the ExpSin case (reference
+    src/prob1_mms_cases.py:280-337, here with the time integrals written out) equal the library's
+    closed-form ExpSin case; malformed programs are refused."""
+    sympy = pytest.importorskip("sympy")
+    from tedd import _symprog as sp
+    z = load("golden_mms.npz")
+    tag = "expsin/nu5x7/stress2"   # a non-uniform mesh, exaggerated model constants
+    consts = np.array(z[f"{tag}/consts"])
+    x, y = z[f"{tag}/x"], z[f"{tag}/y"]
+    c = dict(zip(_ffi.CONST_NAMES, consts))
+    t, X, Y = sympy.symbols("t x y", real=True)
+    W = sympy.sin(sympy.pi * X) * sympy.sin(sympy.pi * Y)
+    a = 2 * sympy.pi ** 2 * sympy.Float(c["DT"])
+    T = sympy.exp(-a * t) * W
+    cl = -sympy.exp(-t) * W
+    cd = sympy.exp(-t) * W
+    s_ = sympy.Symbol("s", real=True)
+    cp = W * sympy.exp(sympy.integrate((-c["K1"] * (1 + cl) - c["K2"] * T).subs(t, s_), (s_, 0, t)))
+    cs = c["r_sp"] * W * sympy.exp(sympy.integrate((-c["Kd"] * (c["Sd"] - cd) * (1 + cl)).subs(t, s_), (s_, 0, t)))
+    named = {}
+    for name, e in {"cp": cp, "T": T, "cl": cl, "cd": cd, "cs": cs}.items():
+        dx, dy = sympy.diff(e, X), sympy.diff(e, Y)
+        named.update({name: e, "dt_" + name: sympy.diff(e, t), "dx_" + name: dx, "dy_" + name: dy,
+                      "lap_" + name: sympy.diff(dx, X) + sympy.diff(dy, Y)})
+    node, cell = sp.lower_case(named, t, X, Y)
+    kw = dict(model_kind=2, reaction_kind=REACT_OF[react], eta=50.0 if react == "reg" else 0.0)
+    prog = _ffi.Context(x, y, consts, mms_case=_ffi.MMS_PROGRAM, **kw)
+    ref = _ffi.Context(x, y, consts, mms_case=_ffi.MMS_EXPSIN, **kw)
+    with pytest.raises(ValueError):
+        prog.eval_exact(0.1)  # no program yet
+    prog.set_mms_program(0, *node)
+    prog.set_mms_program(1, *cell)
+    worst = 0.0
+    for tt in (0.0, 0.37):
+        for what in range(5):
+            for p_, r_ in zip(prog.eval_mms(tt, what), ref.eval_mms(tt, what)):
+                np.testing.assert_allclose(p_, r_, rtol=0, atol=2e-13, equal_nan=True)
+        for p_, r_ in zip(prog.eval_forcing(tt), ref.eval_forcing(tt)):
+            worst = max(worst, float(np.max(np.abs(p_ - r_))))
+    assert worst < 1e-13, worst
+    # steps, device-resident advance with norms, residuals
+    for ctx in (prog, ref):
+        ctx.set_state_exact(0.0)
+    dt = 0.01
+    ea = prog.advance(0.0, dt, 3, integrator=1)
+    eb = ref.advance(0.0, dt, 3, integrator=1)
+    np.testing.assert_allclose(ea, eb, rtol=1e-8, atol=1e-28)
+    for p_, r_ in zip(prog.get_state(), ref.get_state()):
+        np.testing.assert_allclose(p_, r_, rtol=0, atol=1e-14)
+    for p_, r_ in zip(prog.get_residuals(), ref.get_residuals()):
+        np.testing.assert_allclose(p_, r_, rtol=0, atol=1e-14)
+    for ctx in (prog, ref):
+        ctx.step_feuler(3 * dt, 1e-4)
+    for p_, r_ in zip(prog.get_state(), ref.get_state()):
+        np.testing.assert_allclose(p_, r_, rtol=0, atol=1e-14)
+    # malformed programs
+    code, cst, nreg = node
+    bad = code.copy()
+    bad[0] = (sp.OP_ADD) | (3 << 8) | (200 << 16) | (1 << 24)          # operand register out of range
+    for args in ((0, bad, cst, nreg), (0, code, cst, 2), (0, code, cst, 200), (0, code, cst[:1], nreg),
+                 (2, code, cst, nreg), (0, code[:-1], cst, nreg), (1, code, cst, nreg)):
+        with pytest.raises(ValueError):
+            prog.set_mms_program(*args)
+    with pytest.raises(ValueError):
+        ref.set_mms_program(0, *node)  # not a program context
+    prog.close()
+    ref.close()
 
 
 # ---------------------------------------------------------------------------------- sub-steps

@@ -23,6 +23,12 @@ struct CpuBackend {
     void* alloc(size_t bytes) { return std::calloc(bytes ? bytes : 1, 1); }
     void free(void* p) { std::free(p); }
     void memset0(void* p, size_t bytes) { std::memset(p, 0, bytes); }
+    template <class F>
+    void nodes_prog(int, const F& f, int r0, int r1, int ncols, int n_regs) {
+        std::vector<double> regs((size_t)n_regs);
+        for (int li = r0; li < r1; ++li)
+            for (int j = 0; j < ncols; ++j) f(li, j, regs.data(), 1);
+    }
     void step_reset(double* red, int nred, int) { std::memset(red, 0, nred * sizeof(double)); }
     void h2d(void* d, const void* s, size_t b) { std::memcpy(d, s, b); }
     void d2h(void* d, const void* s, size_t b) { std::memcpy(d, s, b); }

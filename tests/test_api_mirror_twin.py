@@ -100,10 +100,12 @@ def test_integrator_pieces_called_on_their_own(kind):
     ac.check_integrator_pieces(kind)
 
 
-# ---- cases given as SymPy expressions: forcing evaluated on the host and streamed
+# ---- cases given as SymPy expressions: run on the device as expression programs, or evaluated on the
+# host and streamed
+@pytest.mark.parametrize("device_program", [True, False])
 @pytest.mark.parametrize("kind", ["reg", "cs3", "hcs"])
-def test_symbolic_case_equals_builtin_case(kind):
-    ac.check_symbolic_case_equals_builtin(kind)
+def test_symbolic_case_equals_builtin_case(kind, device_program):
+    ac.check_symbolic_case_equals_builtin(kind, device_program)
 
 
 @pytest.mark.parametrize("cs_initial,cs_slope", [(1.0, -0.5), (0.1, -15.0), (-0.2, -0.5)])

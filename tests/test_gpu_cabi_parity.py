@@ -80,6 +80,12 @@ def test_hcs_corrector_reports_nonpositive_denominator():
     cc.check_hcs_denominator_error()
 
 
+# ---- exact solutions given as expression programs (TEDD_MMS_PROGRAM)
+@pytest.mark.parametrize("react", ["reg", "cs3", "hcs"])
+def test_mms_program_equals_closed_form(react):
+    cc.check_mms_program(react)
+
+
 # ---- the pieces of a predictor-corrector step called on their own
 @pytest.mark.parametrize("streamed", [False, True], ids=["closed_form", "streamed"])
 @pytest.mark.parametrize("tag", cc.tags("golden_substeps.npz", "/t0"))
