@@ -114,12 +114,14 @@ __global__ void __launch_bounds__(256) k_nodes_sum(const F f, int r0, int r1, in
     if (wave == 0 && lane < F::NR)
         partials[(size_t)blockIdx.x * F::NR + lane] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
+// one wave per reduced quantity (blockDim = 64 x nr): lane l adds the partials l, l+64, ... in that
+// order, then the lanes are combined by a fixed butterfly -- the same order on every run
 __global__ void k_sum_final(const double* partials, int nblocks, int nr, double* out) {
-    const int k = threadIdx.x;
-    if (k >= nr) return;
+    const int k = threadIdx.y;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * nr + k];
-    out[k] = s;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * nr + k];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[k] = s;
 }
 
 // ---- cs corrector (RegHCsTriple): cp trapezoid + per-node scalar Newton for cs with the
@@ -474,7 +476,7 @@ struct HipBackend {
         int tx, nt, nb;
         tiling(r0, r1, ncols, tx, nt, nb);
         hipLaunchKernelGGL(k_nodes_sum<F>, dim3(nb), dim3(kTileX, kTileY), 0, stream, f, r0, r1, ncols, tx, nt, d_partials);
-        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64), 0, stream, d_partials, nb, (int)F::NR, dev_out);
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64, F::NR), 0, stream, d_partials, nb, (int)F::NR, dev_out);
         TEDD_HIP(hipGetLastError());
     }
     // one launch of the register-resident Newton solve chain (tedd_strip.hpp)
