@@ -25,8 +25,8 @@ def test_classes_instantiation():
 @pytest.mark.parametrize("case,levels,rel", [
     ("expsin", (2, 4, 8, 16, 32, 64, 128, 256), 2e-9),      # N=256: the published finest-mesh run (41 steps)
     ("pol", (2, 4, 8, 16, 32, 64, 128, 256), 5e-6),
-    ("peaks_fast1e1", (2, 4, 8, 16, 32, 64), 2e-9),
-    ("nfs_h2_h3", (2, 4, 8, 16, 32, 64), 2e-9)])
+    ("peaks_fast1e1", (2, 4, 8, 16, 32, 64, 128, 256), 2e-9),   # N=256: 4096 steps to Tf=1
+    ("nfs_h2_h3", (2, 4, 8, 16, 32, 64, 128, 256), 2e-9)])      # the full spatial sweep of the notebook
 def test_published_notebook_errors(case, levels, rel):
     ac.check_published_errors(case, levels, rel)
 
