@@ -127,6 +127,13 @@ int tedd_set_state_exact(tedd_ctx* ctx, double t);
 int tedd_set_forcing(tedd_ctx* ctx, int32_t which, const double* fcp, const double* fT, const double* fcl,
                      const double* fcd, const double* fcs);
 
+/* Evaluate the forcing arrays of time level t ahead of the step that needs them, keeping the arrays of
+ * level keep_t (the time the next step starts from).  No counterpart in the reference (it evaluates its
+ * lambdified forcing inside every step, src/prob1base.py:2313-2425): the forcing does not depend on the
+ * state, so a multi-GPU driver enqueues this before it exchanges ghost rows and the launch overlaps the
+ * transfer.  A no-op when the forcing is streamed or evaluated inside the step kernels. */
+int tedd_prefetch_forcing(tedd_ctx* ctx, double t, double keep_t);
+
 /* One predictor-corrector step of P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_{RegHCsTriple,CsTriple}
  * (src/prob1base.py:3117-3149 with 2953-3115, 3174-3219, 3631-3702).  The 5-diagonal systems the
  * reference solves with spsolve (src/prob1base.py:2103,2130) are solved by matrix-free Jacobi

@@ -125,6 +125,9 @@ int tedd_state_device_ptrs(tedd_ctx* ctx, void* ptrs[5]) {
         for (int v = 0; v < 5; ++v) ptrs[v] = C.cur[v];
     });
 }
+int tedd_prefetch_forcing(tedd_ctx* ctx, double t, double keep_t) {
+    return guarded(ctx, [&](auto& C) { C.prefetch_forcing(t, keep_t); });
+}
 int tedd_ghosts_refreshed(tedd_ctx* ctx) {
     return guarded(ctx, [&](auto& C) { C.mark_state_exchanged(); });
 }

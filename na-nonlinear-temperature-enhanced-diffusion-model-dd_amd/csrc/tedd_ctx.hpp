@@ -812,7 +812,7 @@ public:
                 predict_makes_f1 = true;  // the predictor launch evaluates the t1 set (step_pc_impl)
                 for (int v = 0; v < 5; ++v) B((k1 ? SF10 : SF00) + v);
                 fset_time[k1] = t0 + dt;
-            } else {
+            } else if (fset_time[k1] != t0 + dt) {  // (already there after prefetch_forcing)
                 fill_forcing_set(t0 + dt, k1);
             }
             fset[0] = k0;
@@ -828,6 +828,18 @@ public:
             return;
         }
         dispatch(op);
+    }
+    // Evaluate the forcing arrays of a coming time level now, into the set that does not hold
+    // `keep_t` (the level the next step starts from).  The forcing does not depend on the state, so a
+    // caller that exchanges ghost rows between steps can overlap this launch with the transfer.
+    // No effect when the forcing is streamed, evaluated inside the step kernels, or made by the
+    // predictor launch.
+    void prefetch_forcing(double t, double keep_t) {
+        if (mms_case == CASE_STREAM) return;
+        if (!(opt_cache_forcing || mms_case == CASE_PROG) || fuse_forcing_now()) return;
+        if (fset_time[0] == t || fset_time[1] == t) return;
+        const int k = (fset_time[0] == keep_t) ? 1 : 0;
+        fill_forcing_set(t, k);
     }
     void fill_forcing_set(double t, int k) {
         ForcingOp op{this, t, {B((k ? SF10 : SF00)), B((k ? SF10 : SF00) + 1), B((k ? SF10 : SF00) + 2),

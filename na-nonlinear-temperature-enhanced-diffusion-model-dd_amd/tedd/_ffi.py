@@ -61,6 +61,7 @@ PROTOTYPES = {
     "tedd_get_state": (C.c_int, [C.c_void_p] + [_dptr] * 5),
     "tedd_state_device_ptrs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "tedd_ghosts_refreshed": (C.c_int, [C.c_void_p]),
+    "tedd_prefetch_forcing": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "tedd_set_state_exact": (C.c_int, [C.c_void_p, C.c_double]),
     "tedd_set_forcing": (C.c_int, [C.c_void_p, C.c_int32] + [_dptr] * 5),
     "tedd_step_pc": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32,
@@ -202,6 +203,9 @@ class Context:
         params = list(mms_params) + [0.0] * (8 - len(mms_params))
         p = (C.c_double * 8)(*[float(v) for v in params])
         self._check(self._lib.tedd_set_model(self._h, c, model_kind, float(eta), p))
+
+    def prefetch_forcing(self, t, keep_t):
+        self._check(self._lib.tedd_prefetch_forcing(self._h, float(t), float(keep_t)))
 
     def set_mms_program(self, which, code, consts, n_regs):
         """code: uint32 words, consts: float64 (tedd_set_mms_program; which 0 node program, 1 cell program)."""

@@ -80,7 +80,9 @@ class HaloExchange:
             self._bufs[key] = b
         return b
 
-    def exchange(self, fields):
+    def exchange(self, fields, before_wait=None):
+        """before_wait: called after the sends and receives are posted and before they are waited for
+        (work to enqueue on the compute stream that may run while the rows travel)."""
         s = self.slab
         if s.world == 1:
             return
@@ -88,7 +90,7 @@ class HaloExchange:
         if stage is None:
             stage = fields[0].is_cuda and dist.get_backend(self.group) == "gloo"
         if stage:
-            return self._exchange_staged(fields)
+            return self._exchange_staged(fields, before_wait)
         o_lo, o_hi = s.owned_local
         nf = len(fields)
         pitch = fields[0].shape[1]
@@ -112,14 +114,16 @@ class HaloExchange:
             ops.append(dist.P2POp(dist.isend, send, s.rank + 1, self.group))
             ops.append(dist.P2POp(dist.irecv, recv, s.rank + 1, self.group))
             unpack.append((recv, o_hi, o_hi + s.ghost_hi))
-        for w in dist.batch_isend_irecv(ops):
+        works = dist.batch_isend_irecv(ops)
+        if before_wait is not None:
+            before_wait()
+        for w in works:
             w.wait()
         for recv, a, b in unpack:
             for k, f in enumerate(fields):
                 f[a:b].copy_(recv[k])
 
-
-    def _exchange_staged(self, fields):
+    def _exchange_staged(self, fields, before_wait=None):
         s = self.slab
         o_lo, o_hi = s.owned_local
         ops, unpack = [], []
@@ -137,7 +141,10 @@ class HaloExchange:
             ops += [dist.P2POp(dist.isend, send, s.rank + 1, self.group),
                     dist.P2POp(dist.irecv, recv, s.rank + 1, self.group)]
             unpack.append((recv, o_hi, o_hi + s.ghost_hi))
-        for w in dist.batch_isend_irecv(ops):
+        works = dist.batch_isend_irecv(ops)
+        if before_wait is not None:
+            before_wait()
+        for w in works:
             w.wait()
         for recv, a, b in unpack:
             r = recv.to(fields[0].device)
@@ -176,20 +183,34 @@ class SlabStepper:
         self.slab = slab
         self.device = device
         self.halo = HaloExchange(slab, group)
+        self._wrapped = {}
         if device.type == "cuda":
             ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
 
-    def refresh_ghosts(self):
+    def _fields(self):
+        # the state arrays rotate through a small pool of device buffers: wrap each address once
+        out = []
+        for p in self.ctx.state_device_ptrs():
+            t = self._wrapped.get(int(p))
+            if t is None:
+                t = wrap_device_fields([p], self.ctx.nrows, self.ctx.pitch, self.device)[0]
+                self._wrapped[int(p)] = t
+            out.append(t)
+        return out
+
+    def refresh_ghosts(self, before_wait=None):
         if self.slab.world == 1:
             return
-        ptrs = self.ctx.state_device_ptrs()
-        fields = wrap_device_fields(ptrs, self.ctx.nrows, self.ctx.pitch, self.device)
-        self.halo.exchange(fields)
+        self.halo.exchange(self._fields(), before_wait=before_wait)
         self.ctx.ghosts_refreshed()
 
     def step_pc(self, t0, dt, **kw):
         self.ctx.step_pc(t0, dt, **kw)
-        self.refresh_ghosts()
+        # the forcing of the step after this one does not depend on the state: its launch goes to the
+        # compute stream while the ghost rows travel (the next step starts at t0 + dt and needs the
+        # levels t0 + dt, which is kept, and (t0 + dt) + dt)
+        t1 = t0 + dt
+        self.refresh_ghosts(before_wait=lambda: self.ctx.prefetch_forcing(t1 + dt, t1))
 
     def step_feuler(self, t0, dt):
         self.ctx.step_feuler(t0, dt)

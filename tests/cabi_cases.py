@@ -220,6 +220,37 @@ def check_hcs_denominator_error():
     ctx.close()
 
 
+def check_prefetch_forcing():
+    """tedd_prefetch_forcing between steps (what the slab stepper does while ghost rows travel) leaves
+    every result as it is, whichever way the forcing reaches the step kernels."""
+    z = load("golden_steps.npz")
+    tag = "pc_reg/expsin/N8"
+    x, y, consts = z[f"{tag}/x"], z[f"{tag}/y"], z[f"{tag}/consts"]
+    dt = float(z[f"{tag}/dt"])
+    out = {}
+    for name, opts, prefetch in (("plain", {}, False), ("fused+prefetch", {}, True), ("launch", {"fuse_forcing": 0}, False),
+                                 ("launch+prefetch", {"fuse_forcing": 0}, True),
+                                 ("in_kernels+prefetch", {"cache_forcing": 0}, True)):
+        ctx = _ffi.Context(x, y, consts, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=float(z[f"{tag}/eta"]),
+                           mms_case=_ffi.MMS_EXPSIN)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.set_state_exact(0.0)
+        t = 0.0
+        for _ in range(4):
+            ctx.step_pc(t, dt, jacobi_sweeps=(30, 20, 20))
+            t1 = t + dt
+            if prefetch:
+                ctx.prefetch_forcing(t1 + dt, t1)
+                ctx.prefetch_forcing(t1 + dt, t1)  # a second call finds the level in place
+            t = t1
+        out[name] = ctx.get_state()
+        ctx.close()
+    for name in out:
+        for a, b in zip(out[name], out["plain"]):
+            np.testing.assert_array_equal(a, b, err_msg=name)
+
+
 # ---------------------------------------------------------------------------------- expression programs
 def check_mms_program(react):
     """TEDD_MMS_PROGRAM through the C ABI: the exact solution, its derivatives, the five forcing arrays

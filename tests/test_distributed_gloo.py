@@ -46,7 +46,7 @@ def test_partition_covers_all_rows():
         partition_rows(9, 2, 0, 0)
 
 
-def _worker(rank, world, port, case, N, M, nsteps, kind, consts, sweeps, ghost, out_dir):
+def _worker(rank, world, port, case, N, M, nsteps, kind, consts, sweeps, ghost, out_dir, options):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -59,6 +59,8 @@ def _worker(rank, world, port, case, N, M, nsteps, kind, consts, sweeps, ghost, 
         ctx = _ffi.Context(x, y, consts, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
                            mms_case=case, row_lo=slab.row_lo, row_hi=slab.row_hi, ghost=slab.ghost)
         assert ctx.nrows == slab.local_rows and ctx.row_offset == slab.row_offset
+        for name, value in options.items():
+            ctx.set_option(name, value)
         stepper = SlabStepper(ctx, slab, torch.device("cpu"))
         ctx.set_state_exact(0.0)
         dt, t = 0.01, 0.0
@@ -104,15 +106,20 @@ def _single(case, N, M, nsteps, kind, consts, sweeps):
     return out, np.array(norms)
 
 
+# "forcing_launch": the forcing arrays of a time level come from a launch of their own, which the slab
+# stepper enqueues ahead of time while the ghost rows travel (as on slabs too large for the predictor
+# launch to make them)
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("kind,case,consts", [("pc", 1, NB_A), ("pc", 0, STRESS), ("fe", 2, NB_A)])
-def test_slab_run_equals_single_domain(world, kind, case, consts, tmp_path):
+@pytest.mark.parametrize("kind,case,consts,options", [("pc", 1, NB_A, {}), ("pc", 0, STRESS, {}), ("fe", 2, NB_A, {}),
+                                                      ("pc", 1, NB_A, {"fuse_forcing": 0})],
+                         ids=["pc-expsin", "pc-pol-stress", "fe-peaks", "pc-expsin-forcing_launch"])
+def test_slab_run_equals_single_domain(world, kind, case, consts, options, tmp_path):
     N, M, nsteps = 47, 21, 4
     sweeps = [4, 3, 2]
     ghost = sum(sweeps) + 2 if kind == "pc" else 1
     ref_state, ref_norms = _single(case, N, M, nsteps, kind, consts, sweeps)
     port = 29500 + (os.getpid() % 2000) + world
-    mp.spawn(_worker, args=(world, port, case, N, M, nsteps, kind, consts, sweeps, ghost, str(tmp_path)),
+    mp.spawn(_worker, args=(world, port, case, N, M, nsteps, kind, consts, sweeps, ghost, str(tmp_path), options),
              nprocs=world, join=True)
     rows = 0
     for r in range(world):

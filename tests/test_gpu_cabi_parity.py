@@ -80,6 +80,10 @@ def test_hcs_corrector_reports_nonpositive_denominator():
     cc.check_hcs_denominator_error()
 
 
+def test_prefetch_forcing_changes_nothing():
+    cc.check_prefetch_forcing()
+
+
 # ---- exact solutions given as expression programs (TEDD_MMS_PROGRAM)
 @pytest.mark.parametrize("react", ["reg", "cs3", "hcs"])
 def test_mms_program_equals_closed_form(react):
