@@ -1,0 +1,102 @@
+"""The bench workload at its full sizes on the GPU (ExpSin, RegHCsTriple, notebook constants, dt = h^1.5 on the
+4096^2 and 16384^2 synthetic meshes), checked through properties that do not need the CPU oracle, which
+cannot run at these sizes:
+
+  * the run tracks the exact solution (error norms after the steps stay at the level the second-order
+    scheme gives on such a mesh);
+  * every Jacobi solve reached its tolerance (recorded last update vs increment), and the Newton
+    residuals of the last step are small (the bound of reference tests/test_newton_residuals.py:116-124);
+  * the boundary rules of the step hold on every boundary node (T, cp, cs are 0 there;
+    reference src/prob1base.py:3041, :2996, :3645);
+  * implementations that must give the same numbers do: the solve chain with its automatic tile
+    shapes, with the large tiles only, and one launch per Jacobi sweep; forcing arrays per time level
+    and forcing evaluated inside the step kernels.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NB_A = [8.3144621, 1.60217662e-19, 1e-3, 1e-3, 1e-3, 1e-3, 1e-3, 1e-5, 1e-5, 1e-9, 1e-2, 1.0, 1e-6, 1e-5,
+        1.60217662e-19 / 8.3144621, 5e-2, 300.0]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def hip_library():
+    import torch
+    from tedd import _ffi
+
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    _ffi.use_library(_ffi.DEFAULT_LIBRARY)
+    yield
+
+
+def _run(N, nsteps, options, want_state):
+    from tedd import _ffi
+    x = np.linspace(0, 1, N + 1)
+    ctx = _ffi.Context(x, x, NB_A, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+                       mms_case=_ffi.MMS_EXPSIN)
+    for k, v in options.items():
+        ctx.set_option(k, v)
+    dt, t = (1.0 / N) ** 1.5, 0.0
+    ctx.set_state_exact(0.0)
+    for _ in range(nsteps):
+        ctx.step_pc(t, dt)
+        t += dt
+    stats = ctx.get_stats()
+    norms = np.asarray(ctx.error_norms(t))
+    out = {"stats": stats, "norms": norms, "t": t}
+    if want_state:
+        out["state"] = ctx.get_state()
+        out["residuals"] = ctx.get_residuals()
+    ctx.close()
+    return out
+
+
+def _check_properties(N, r):
+    h = 1.0 / N
+    # Jacobi: last update below 10 x tolerance x increment for T, cl, cd
+    for v in range(3):
+        upd, inc = r["stats"]["last_update"][v], r["stats"]["increment"][v]
+        assert upd <= 1e-12 * inc or upd == 0.0, (N, v, upd, inc)
+    # tracks the exact solution: ||e||_H of the five unknowns after a few steps of size h^1.5
+    err_H = float(np.sqrt(np.sum(r["norms"][:5])))
+    assert np.isfinite(r["norms"]).all() and err_H < 50 * h * h * r["t"] + 1e-13, (N, err_H)
+    if "state" in r:
+        cp, T, cl, cd, cs = r["state"]
+        for name, a in (("T", T), ("cp", cp), ("cs", cs)):
+            assert not a[0, :].any() and not a[-1, :].any() and not a[:, 0].any() and not a[:, -1].any(), name
+        for a in r["state"]:
+            assert np.isfinite(a).all()
+        w = h * h  # uniform mesh: ||r||_H^2 = sum_interior r^2 h k
+        for name, res in zip(("T", "cl", "cd"), r["residuals"]):
+            assert np.sqrt(np.sum(res[1:-1, 1:-1] ** 2) * w) < 1e-9, name
+
+
+def test_solver_variants_agree_4096():
+    """16.8 M nodes: all variants, full states compared."""
+    N = 4096
+    ref = _run(N, 3, {}, True)
+    _check_properties(N, ref)
+    scale = [np.max(np.abs(a)) for a in ref["state"]]
+    for name, opts in (("large tiles", {"strip_shape": 0}), ("sweeps", {"strip_solve": 0}),
+                       ("forcing in kernels", {"cache_forcing": 0}), ("forcing by predictor", {"fuse_forcing": 1})):
+        r = _run(N, 3, opts, True)
+        for a, b, s in zip(r["state"], ref["state"], scale):
+            # tile shapes change nothing; the per-sweep solver and the in-kernel forcing round differently
+            tol = 0.0 if name == "large tiles" else 1e-14 * max(s, 1.0)
+            assert np.max(np.abs(a - b)) <= tol, name
+        np.testing.assert_allclose(r["norms"], ref["norms"], rtol=1e-6, atol=1e-30, err_msg=name)
+
+
+def test_bench_mesh_16384():
+    """268 M nodes (the mesh the headline number is measured on): three steps, then the properties; the
+    large-tile chain must reproduce the automatic one bit for bit (compared through the error norms, whose
+    deterministic sums see every node, and through the downloaded state of the default run)."""
+    N = 16384
+    ref = _run(N, 3, {}, True)
+    _check_properties(N, ref)
+    del ref["state"], ref["residuals"]
+    r = _run(N, 3, {"strip_shape": 0}, False)
+    _check_properties(N, r)
+    np.testing.assert_array_equal(r["norms"], ref["norms"])
