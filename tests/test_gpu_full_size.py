@@ -31,10 +31,11 @@ def hip_library():
     yield
 
 
-def _run(N, nsteps, options, want_state):
+def _run(N, nsteps, options, want_state, M=None, stretch=1.0):
     from tedd import _ffi
-    x = np.linspace(0, 1, N + 1)
-    ctx = _ffi.Context(x, x, NB_A, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+    x = np.linspace(0, 1, N + 1) ** stretch
+    y = x if M is None else np.linspace(0, 1, M + 1) ** (1.0 / stretch)
+    ctx = _ffi.Context(x, y, NB_A, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
                        mms_case=_ffi.MMS_EXPSIN)
     for k, v in options.items():
         ctx.set_option(k, v)
@@ -100,3 +101,22 @@ def test_bench_mesh_16384():
     r = _run(N, 3, {"strip_shape": 0}, False)
     _check_properties(N, r)
     np.testing.assert_array_equal(r["norms"], ref["norms"])
+
+
+def test_odd_nonuniform_mesh_variants_agree():
+    """A 1001 x 778-node non-uniform mesh (no dimension a multiple of the tile sizes): every tile shape and
+    chain depth of the solve, the per-sweep solver and both forcing modes give the same state."""
+    N, M = 1000, 777
+    ref = _run(N, 3, {}, True, M=M, stretch=1.15)
+    for a in ref["state"]:
+        assert np.isfinite(a).all()
+    scale = [max(np.max(np.abs(a)), 1.0) for a in ref["state"]]
+    exact = ("shape 0", "shape 1", "shape 2", "shape 1 depth 3", "shape 2 depth 2")
+    for name, opts in (("shape 0", {"strip_shape": 0}), ("shape 1", {"strip_shape": 1}), ("shape 2", {"strip_shape": 2}),
+                       ("shape 1 depth 3", {"strip_shape": 1, "strip_hmax": 3}),
+                       ("shape 2 depth 2", {"strip_shape": 2, "strip_hmax": 2}),
+                       ("sweeps", {"strip_solve": 0}), ("forcing in kernels", {"cache_forcing": 0}),
+                       ("forcing launch", {"fuse_forcing": 0})):
+        r = _run(N, 3, opts, True, M=M, stretch=1.15)
+        for a, b, s in zip(r["state"], ref["state"], scale):
+            assert np.max(np.abs(a - b)) <= (0.0 if name in exact else 1e-14 * s), name
