@@ -505,9 +505,7 @@ public:
     }
     void get_state(double* const h[5]) {
         require_state();
-        for (int v = 0; v < 5; ++v)
-            if (h[v]) download_field(h[v], cur[v]);
-        be.sync();
+        be.d2h_fields(h, cur, 5, ld, ncols, nrows);
     }
     // Install nxt as the state; buffers of the old state that are not reused go back to the pool.
     void commit_state(double* const nxt[5]) {

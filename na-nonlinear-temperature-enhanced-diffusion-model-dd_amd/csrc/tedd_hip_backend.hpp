@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -336,6 +337,9 @@ struct HipBackend {
         free(d_stage);
         d_stage = nullptr;
         stage_elems = 0;
+        if (h_pinned) (void)hipHostFree(h_pinned);
+        h_pinned = nullptr;
+        pinned_elems = 0;
         if (own_stream && stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
@@ -423,6 +427,37 @@ struct HipBackend {
         }
     }
     void sync() { TEDD_HIP(hipStreamSynchronize(stream)); }
+    // Several pitched device fields to dense host arrays, synchronously.  Small fields (a state of a
+    // convergence-study mesh) go through one pinned buffer: one transfer and one wait instead of one per field.
+    double* h_pinned = nullptr;
+    size_t pinned_elems = 0;
+    void d2h_fields(double* const* dst, const double* const* src, int count, size_t spitch, int width, int rows) {
+        const size_t n = (size_t)rows * width;
+        int wanted = 0;
+        for (int v = 0; v < count; ++v) wanted += dst[v] != nullptr;
+        if (wanted == 0) return;
+        if (n * wanted * sizeof(double) > ((size_t)32 << 20)) {
+            for (int v = 0; v < count; ++v)
+                if (dst[v]) d2h_2d(dst[v], width, src[v], spitch, width, rows);
+            sync();
+            return;
+        }
+        if (n * wanted > pinned_elems) {
+            if (h_pinned) (void)hipHostFree(h_pinned);
+            h_pinned = nullptr;
+            TEDD_HIP(hipHostMalloc((void**)&h_pinned, n * wanted * sizeof(double), hipHostMallocDefault));
+            pinned_elems = n * wanted;
+        }
+        double* st = stage(n * wanted);
+        int k = 0;
+        for (int v = 0; v < count; ++v)
+            if (dst[v]) copy_rows(st + n * k++, width, src[v], spitch, width, rows);
+        TEDD_HIP(hipMemcpyAsync(h_pinned, st, n * wanted * sizeof(double), hipMemcpyDeviceToHost, stream));
+        sync();
+        k = 0;
+        for (int v = 0; v < count; ++v)
+            if (dst[v]) std::memcpy(dst[v], h_pinned + n * k++, n * sizeof(double));
+    }
 
     // ---- timing record
     hipEvent_t get_event() {

@@ -36,6 +36,10 @@ struct CpuBackend {
         for (int r = 0; r < rows; ++r) std::memcpy(d + r * dp, s + r * sp, (size_t)w * sizeof(double));
     }
     void d2h_2d(double* d, size_t dp, const double* s, size_t sp, int w, int rows) { h2d_2d(d, dp, s, sp, w, rows); }
+    void d2h_fields(double* const* dst, const double* const* src, int count, size_t sp, int w, int rows) {
+        for (int v = 0; v < count; ++v)
+            if (dst[v]) d2h_2d(dst[v], w, src[v], sp, w, rows);
+    }
     void sync() {}
     void profile_enable(bool) {}
     void profile_collect() {}
