@@ -394,6 +394,43 @@ template <int CASE>
 TEDD_HD double mms_fcp_cellavg(const ModelC& m, const MmsTime& tm, const MmsTabs& tb, int li, int j) {
     const double w[3] = {5.0 / 9.0, 8.0 / 9.0, 5.0 / 9.0};
     double acc = 0.0;
+    if (CASE == CASE_EXPSIN) {
+        // The nine exponentials of the exact cp in one block: the short series of tedd_exp for all of
+        // them, and the library routine only if some lane of the wave has an argument outside the
+        // range of the series (value by value the result is what tedd_exp returns; nine separate
+        // range checks would cut the quadrature into as many branch regions).
+        double W[9], E[9];
+        bool small = true;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            W[q] = tab_xq(tb, 0, q / 3, li) * tab_yq(tb, 0, q % 3, j);
+            E[q] = tm.s[5] + tm.s[3] * W[q];
+            small = small && fabs(E[q]) < 0x1p-10;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        const bool all_small = __all(small);
+#else
+        const bool all_small = small;
+#endif
+        double P[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const double x = E[q];
+            P[q] = 1.0 + x * (1.0 + x * (0.5 + x * (1.0 / 6.0 + x * (1.0 / 24.0 + x * (1.0 / 120.0)))));
+        }
+        if (!all_small) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) P[q] = (fabs(E[q]) < 0x1p-10) ? P[q] : exp(E[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const double cp = W[q] * P[q];
+            const double cp_t = cp * (-m.K1 + tm.s[4] * W[q]);
+            const double cl = -tm.s[1] * W[q], T = tm.s[0] * W[q];
+            acc += w[q / 3] * w[q % 3] * (cp_t - (-cp * (m.K1 * (1.0 + cl) + m.K2 * T)));
+        }
+        return 0.25 * acc;
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
