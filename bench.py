@@ -142,6 +142,49 @@ def study_mesh_run(N=256, steps=400, warmup=20):
             "steps_per_s": steps / el, "ms_per_step": 1e3 * el / steps, "jacobi_sweeps": stats["sweeps"]}
 
 
+def other_configs_run():
+    """The smaller configurations of the study: latency of one full step on the mid-resolution mesh, and the
+    whole run of the stress case (SlowlyChangingPeaks_Fast1e1, N=256, Tf=1: 4096 steps with the error norms of
+    the harness after every step)."""
+    from tedd import _ffi
+    out = {}
+    N = 32
+    x = np.linspace(0, 1, N + 1)
+    ctx = _ffi.Context(x, x, consts_vec(NB_A), model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+                       mms_case=_ffi.MMS_EXPSIN)
+    dt = (1.0 / N) ** 1.5
+    ctx.set_state_exact(0.0)
+    ctx.advance(0.0, dt, 20, want_errors=False)
+    ctx.sync()
+    lat = []
+    t = 20 * dt
+    for _ in range(200):
+        t0 = time.perf_counter()
+        ctx.step_pc(t, dt)
+        ctx.sync()
+        lat.append(time.perf_counter() - t0)
+        t += dt
+    ctx.close()
+    out["expsin_N32_one_step"] = {"latency_us_median": 1e6 * float(np.median(lat)),
+                                  "workload": "ExpSin N=32, one predictor-corrector step, enqueue to completion"}
+    N = 256
+    x = np.linspace(0, 1, N + 1)
+    nb_b = dict(NB_A, Dl_max=8.01e-4, Dd_max=2.46e-6)
+    ctx = _ffi.Context(x, x, consts_vec(nb_b), model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+                       mms_case=_ffi.MMS_PEAKS, mms_params=(1.0, 10.0))
+    dt = (1.0 / N) ** 1.5
+    ctx.set_state_exact(0.0)
+    t0 = time.perf_counter()
+    series = ctx.advance(0.0, dt, 4096, integrator=1)
+    el = time.perf_counter() - t0
+    ctx.close()
+    assert np.isfinite(series).all()
+    out["peaks_fast1e1_N256_full_run"] = {"steps": 4096, "seconds": el, "steps_per_s": 4096 / el,
+                                          "workload": "SlowlyChangingPeaks_Fast1e1 N=256, Tf=1, dt=h^1.5, error norms "
+                                                      "after every step (the notebook's finest level)"}
+    return out
+
+
 def cpu_baseline_run(N=256, steps=20):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import tedd_oracle as orc
@@ -308,6 +351,7 @@ def main():
         sm["speedup_vs_cpu_baseline"] = sm["steps_per_s"] / cb["value"]
         out["study_mesh"] = sm
         out["cpu_baseline"] = cb
+        out["other_configs"] = other_configs_run()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
