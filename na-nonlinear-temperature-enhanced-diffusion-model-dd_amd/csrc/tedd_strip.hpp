@@ -254,12 +254,21 @@ k_solve_strip(const StripArgs A) {
         below = seam[par][min(wave + 1, W - 1)][0][lane];  // row row0+R (unused for the last wave)
         par ^= 1;
     };
+    // (explicit fused multiply-adds in a fixed order: left to the compiler, the contraction of these sums
+    // differs between instantiations of the kernel, and the tile shapes would no longer agree bit for bit)
     auto update = [&](int k, double prev, double cur, double nxt) {
         if (LEAN) {
             const double2 rc = rowc[R * wave + k];
-            return b[k] + inv[k] * (rc.x * nxt + rc.y * prev + on * lane_above(cur) + os * lane_below(cur));
+            double acc = rc.y * prev;
+            acc = fma(rc.x, nxt, acc);
+            acc = fma(on, lane_above(cur), acc);
+            acc = fma(os, lane_below(cur), acc);
+            return fma(inv[k], acc, b[k]);
         }
-        return b[k] + ce[k] * nxt + cw[k] * prev + cn[k] * lane_above(cur) + cs[k] * lane_below(cur);
+        double acc = fma(ce[k], nxt, b[k]);
+        acc = fma(cw[k], prev, acc);
+        acc = fma(cn[k], lane_above(cur), acc);
+        return fma(cs[k], lane_below(cur), acc);
     };
     // (lean rows have the registers to fuse the final sweep with the store; full rows do it in place)
     constexpr bool FUSE_FINAL = LAST && LEAN;

@@ -120,3 +120,40 @@ def test_odd_nonuniform_mesh_variants_agree():
         r = _run(N, 3, opts, True, M=M, stretch=1.15)
         for a, b, s in zip(r["state"], ref["state"], scale):
             assert np.max(np.abs(a - b)) <= (0.0 if name in exact else 1e-14 * s), name
+
+
+@pytest.mark.parametrize("N,M", [(63, 64), (131, 257), (300, 301)])
+@pytest.mark.parametrize("react", [0, 1, 2])
+def test_tile_shapes_and_depths_bit_identical(N, M, react):
+    """Random non-uniform meshes whose sizes straddle the tile edges, large steps (increments 1e-3 of the
+    fields, so that a last-bit difference of an increment shows in the unknown): every tile shape and chain
+    depth of the solve gives the same bits, and the per-sweep solver the same values to 1e-14.  (This needs
+    the build's -ffp-contract=on: with cross-statement contraction the instantiations of the kernel round
+    the matrix rows differently.)"""
+    from tedd import _ffi
+    rng = np.random.default_rng(7 + N)
+    x = np.concatenate([[0.0], np.cumsum(0.5 + rng.random(N))])
+    y = np.concatenate([[0.0], np.cumsum(0.5 + rng.random(M))])
+    x, y = x / x[-1], y / y[-1]
+
+    def run(opts):
+        ctx = _ffi.Context(x, y, NB_A, model_kind=2, reaction_kind=react, eta=50.0 if react == 1 else 0.0,
+                           mms_case=_ffi.MMS_EXPSIN)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.set_state_exact(0.0)
+        for k in range(2):
+            ctx.step_pc(k * 2e-3, 2e-3, jacobi_sweeps=(23, 11, 7))
+        out = ctx.get_state()
+        ctx.close()
+        return out
+
+    ref = run({"strip_solve": 0})
+    first = None
+    for shape in (0, 1, 2):
+        for hmax in (1, 3, 10):
+            out = run({"strip_shape": shape, "strip_hmax": hmax})
+            first = out if first is None else first
+            for a, b, c in zip(out, first, ref):
+                np.testing.assert_array_equal(a, b, err_msg=f"shape {shape} depth {hmax}")
+                assert np.max(np.abs(a - c)) <= 1e-14 * max(1.0, np.max(np.abs(c)))
