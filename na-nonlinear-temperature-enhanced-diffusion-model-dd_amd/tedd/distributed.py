@@ -62,6 +62,15 @@ def partition_rows(n_rows: int, world: int, rank: int, ghost: int) -> Slab:
     return Slab(rank, world, n_rows, lo, hi, ghost if world > 1 else 0)
 
 
+def _copy_many(dsts, srcs):
+    """dst[k] <- src[k] for lists of equally shaped tensors, as one multi-tensor launch where torch has it."""
+    try:
+        torch._foreach_copy_(dsts, srcs)
+    except (AttributeError, RuntimeError, TypeError):
+        for d, s in zip(dsts, srcs):
+            d.copy_(s)
+
+
 class HaloExchange:
     """Refreshes the ghost rows of a list of (local_rows x pitch) tensors with one send and one
     receive per neighbour (all fields packed into one message)."""
@@ -99,8 +108,7 @@ class HaloExchange:
         if s.rank > 0:
             n_send = min(s.ghost, s.n_rows - s.row_lo)  # = neighbour's ghost_hi
             send = self._buf("send_lo", (nf, n_send, pitch), fields[0])
-            for k, f in enumerate(fields):
-                send[k].copy_(f[o_lo:o_lo + n_send])
+            _copy_many([send[k] for k in range(nf)], [f[o_lo:o_lo + n_send] for f in fields])
             recv = self._buf("recv_lo", (nf, s.ghost_lo, pitch), fields[0])
             ops.append(dist.P2POp(dist.isend, send, s.rank - 1, self.group))
             ops.append(dist.P2POp(dist.irecv, recv, s.rank - 1, self.group))
@@ -108,8 +116,7 @@ class HaloExchange:
         if s.rank < s.world - 1:
             n_send = min(s.ghost, s.row_hi)  # = neighbour's ghost_lo
             send = self._buf("send_hi", (nf, n_send, pitch), fields[0])
-            for k, f in enumerate(fields):
-                send[k].copy_(f[o_hi - n_send:o_hi])
+            _copy_many([send[k] for k in range(nf)], [f[o_hi - n_send:o_hi] for f in fields])
             recv = self._buf("recv_hi", (nf, s.ghost_hi, pitch), fields[0])
             ops.append(dist.P2POp(dist.isend, send, s.rank + 1, self.group))
             ops.append(dist.P2POp(dist.irecv, recv, s.rank + 1, self.group))
@@ -120,8 +127,7 @@ class HaloExchange:
         for w in works:
             w.wait()
         for recv, a, b in unpack:
-            for k, f in enumerate(fields):
-                f[a:b].copy_(recv[k])
+            _copy_many([f[a:b] for f in fields], [recv[k] for k in range(nf)])
 
     def _exchange_staged(self, fields, before_wait=None):
         s = self.slab

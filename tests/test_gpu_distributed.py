@@ -75,3 +75,32 @@ def test_two_slabs_equal_single_slab(tmp_path, options):
         lo, hi = int(z["lo"]), int(z["hi"])
         for k in range(5):
             np.testing.assert_array_equal(z[f"f{k}"], ref[k][lo:hi])
+
+
+def test_halo_pack_and_unpack_on_device_views():
+    """The pack / unpack copies of the RCCL exchange path (multi-tensor copies between ghost-row slices of the
+    library's own device arrays, wrapped through their raw addresses, and the message buffers)."""
+    from tedd import _ffi
+    from tedd.distributed import _copy_many, wrap_device_fields
+    _ffi.use_library(_ffi.DEFAULT_LIBRARY)
+    x = np.linspace(0, 1, 41)
+    y = np.linspace(0, 1, 24)
+    ctx = _ffi.Context(x, y, NB_A, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+                       mms_case=_ffi.MMS_EXPSIN)
+    ctx.set_state_exact(0.1)
+    ref = ctx.get_state()
+    dev = torch.device("cuda", 0)
+    fields = wrap_device_fields(ctx.state_device_ptrs(), ctx.nrows, ctx.pitch, dev)
+    send = torch.empty((5, 7, ctx.pitch), dtype=torch.float64, device=dev)
+    _copy_many([send[k] for k in range(5)], [f[3:10] for f in fields])
+    torch.cuda.synchronize()
+    for k in range(5):
+        np.testing.assert_array_equal(send[k].cpu().numpy()[:, :24], ref[k][3:10])
+    _copy_many([f[30:37] for f in fields], [send[k] for k in range(5)])   # rows 3..9 -> rows 30..36
+    torch.cuda.synchronize()
+    ctx.ghosts_refreshed()
+    out = ctx.get_state()
+    for k in range(5):
+        np.testing.assert_array_equal(out[k][30:37], ref[k][3:10])
+        np.testing.assert_array_equal(out[k][:30], ref[k][:30])
+    ctx.close()
