@@ -1,0 +1,64 @@
+"""bench.py: the bookkeeping behind its numbers (CPU) and the shape of the line it prints (GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_array_passes_of_the_default_step():
+    sweeps = bench.pick_sweeps(16384, (1.0 / 16384) ** 1.5, 1e-13)
+    assert sweeps == [20, 7, 5]
+    arrays, chains = bench.arrays_per_launch("strip", 1, sweeps, 10, 0)
+    assert arrays["predict"] == 21 and arrays["forcing"] == 5 and arrays["cs_newton"] == 8
+    assert chains["solve_T"] == {"launches_per_solve": 2, "arrays_per_solve": 8}
+    launches = {"forcing": 1, "predict": 1, "rhs_cl": 1, "rhs_cd": 1, "cs_newton": 1,
+                "solve_T": 2, "solve_cl": 1, "solve_cd": 1}
+    assert sum(arrays[k] * n for k, n in launches.items()) == 71
+    # the predictor launch makes the forcing arrays itself on small slabs: no forcing launch, 5 more writes
+    fused, _ = bench.arrays_per_launch("strip", 1, sweeps, 10, 1)
+    assert "forcing" not in fused and fused["predict"] == 23
+
+
+def test_sweep_counts_follow_the_contraction_bound():
+    for N, expect in ((256, [10, 5, 4]), (4096, [15, 6, 5])):
+        assert bench.pick_sweeps(N, (1.0 / N) ** 1.5, 1e-13) == expect
+
+
+def test_committed_pmc_summary_feeds_the_traffic_figure():
+    cfg = {"mesh_N": 16384, "solver": "strip", "sweeps_per_launch": 10, "forcing": "arrays per time level"}
+    tr = bench.pmc_traffic("predict", cfg)
+    assert tr is not None and tr["source"].startswith("profiles/")
+    algorithmic = 8.0 * 16385 * 16385 * 21
+    assert algorithmic < tr["bytes_per_launch"] < 1.35 * algorithmic
+    assert bench.pmc_traffic("predict", dict(cfg, mesh_N=123)) is None
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_line_with_the_agreed_fields():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mesh", "1024", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] == pytest.approx(1e3 / d["ms_per_step"], rel=1e-9)
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.0 < r["frac"] < 1.0
+    assert "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    assert np.isfinite(d["config"]["error_H_after_run"])
