@@ -87,6 +87,14 @@ def check_published_errors(case_name, levels, rel):
         for v, val in lev["per_variable"].items():
             assert summ.per_variable_sup_errors[v] == pytest.approx(val, rel=1e-4, abs=1e-16), (case_name, N, v)
         out.append(summ.overall_combined_error)
+    # observed 3-point rates of this sweep against the ones the notebook prints (3 decimals)
+    all_levels = [lev["N"] for lev in PUBLISHED[case_name]["levels"]]
+    if len(out) >= 3 and list(levels)[-len(out):] == all_levels[-len(out):] and len(out) == len(all_levels):
+        from tedd.cvg_studies_base import calculate_observed_rates
+        rates = [r for r, _status in calculate_observed_rates(out, 2.0)]
+        printed = PUBLISHED[case_name]["rates_3pt"]
+        for mine, ref in zip(rates[-len(printed):], printed):
+            assert mine == pytest.approx(ref, abs=2e-3), (case_name, rates, printed)
     return out
 
 
