@@ -129,6 +129,34 @@ def check_reference_temporal_study(rel):
         assert summ.overall_combined_error == pytest.approx(row["overall"], rel=rel), row["dt"]
 
 
+STUDIES = json.load(open(os.path.join(GOLDEN, "golden_studies.json")))
+
+
+def check_run_convergence_studies(label, rel, fused=True):
+    """The legacy study runner (reference src/cvg_studies_base.py:319-486) against its own report from
+    the reference (tests/golden/make_golden.py --only studies): errors, 3-point rates and status strings."""
+    import tedd.cvg_studies_base as cvg
+    ref = STUDIES["studies"][label]
+    family = ref["family"]
+    cfg = (getattr(p1, f"SemiDiscreteField_{family}"), CASES[ref["case"]][0], getattr(p1, f"ForcingTerms_{family}"),
+           getattr(p1, f"P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_{family}"), label)
+    params = dict(STUDIES["params"], model=model_of(ref["model_set"]), fused=fused)
+    rep = cvg.run_convergence_studies([cfg], params, verbose=False)
+    assert list(rep) == [label]
+    for study in ("spatial", "temporal"):
+        mine, theirs = rep[label][study], ref["report"][study]
+        assert set(mine) == {"errors", "rates", "statuses"}
+        assert mine["errors"] == pytest.approx(theirs["errors"], rel=rel), (label, study)
+        assert mine["statuses"] == theirs["statuses"], (label, study)
+        for a, b in zip(mine["rates"], theirs["rates"]):
+            if b is None:
+                assert np.isnan(a)
+            else:
+                # a rate is a log of a ratio of error differences: it amplifies rel by E/(E_k - E_k+1)
+                assert a == pytest.approx(b, abs=1e-6), (label, study, mine["rates"], theirs["rates"])
+    return rep
+
+
 def check_fused_equals_stepwise(case_name, N, nsteps_Tf):
     """The device-fused time loop + norms and the reference's step-by-step loop agree."""
     cls, mset, _ = CASES[case_name]

@@ -22,6 +22,8 @@ The fixtures are plain data (inputs + the reference's outputs, float64 .npz and
                       (initial_*_pred, newton_step_*, corrector_*_step) for the three integrators
   golden_symbolic.npz forcing arrays and integrator steps for the three cases the reference states
                       symbolically only (StiffExpDecay, PolWithOscilatingTime, CsZeroCrossing)
+  golden_studies.json the report of cvg_studies_base.run_convergence_studies (legacy study runner) for
+                      two small CsTriple / HCsTriple studies
   golden_scalars.json MMSTrial.run_for_errors summaries (only with --scalars; slow)
   published_notebook_errors.json   numbers printed in the reference's executed
                       notebooks (parsed from the .ipynb stream outputs)
@@ -510,6 +512,37 @@ def gen_symbolic():
 
 
 # ----------------------------------------------------------------------------------
+def study_setups():
+    return {
+        "cstriple_pol": ("CsTriple", "pol", "nb_b"),
+        "hcstriple_expsin": ("HCsTriple", "expsin", "nb_a"),
+    }
+
+
+STUDY_PARAMS = dict(Tf=0.02, N_base_spatial=4, num_spatial_refinements=4, dt_fixed_spatial=2.5e-3,
+                    N_fixed_temporal=16, dt_base_temporal=1e-2, num_temporal_refinements=4)
+
+
+def gen_studies():
+    import contextlib
+    import io
+
+    import cvg_studies_base as cvg
+    out = {"params": STUDY_PARAMS, "studies": {}}
+    for label, (family, cname, mname) in study_setups().items():
+        cfg = (getattr(p1, f"SemiDiscreteField_{family}"), MMS_CASES[cname][0], getattr(p1, f"ForcingTerms_{family}"),
+               getattr(p1, f"P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_{family}"), label)
+        with contextlib.redirect_stdout(io.StringIO()):
+            rep = cvg.run_convergence_studies([cfg], dict(STUDY_PARAMS, model=make_model(mname, 2)))
+        out["studies"][label] = {"family": family, "case": cname, "model_set": mname,
+                                 "report": {k: {kk: [None if (isinstance(x, float) and x != x) else x for x in vv]
+                                                for kk, vv in v.items()} for k, v in rep[label].items()}}
+    with open(os.path.join(HERE, "golden_studies.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("golden_studies.json written")
+
+
+# ----------------------------------------------------------------------------------
 def gen_substeps():
     """The methods step() is made of, called one by one in step()'s order (src/prob1base.py:3117-3149)."""
     out = {}
@@ -647,7 +680,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     np.seterr(all="ignore")
-    todo = a.only.split(",") if a.only else ["ops", "mms", "steps", "hcs", "substeps", "symbolic", "published"]
+    todo = a.only.split(",") if a.only else ["ops", "mms", "steps", "hcs", "substeps", "symbolic", "studies", "published"]
     if "ops" in todo:
         gen_ops()
     if "mms" in todo:
@@ -660,6 +693,8 @@ if __name__ == "__main__":
         gen_substeps()
     if "symbolic" in todo:
         gen_symbolic()
+    if "studies" in todo:
+        gen_studies()
     if "published" in todo:
         gen_published()
     if a.scalars:

@@ -127,3 +127,10 @@ def test_symbolic_case_equals_builtin_case(kind, device_program):
 @pytest.mark.parametrize("cs_initial,cs_slope", [(1.0, -0.5), (0.1, -15.0), (-0.2, -0.5)])
 def test_symbolic_cs_ramp_single_step(cs_initial, cs_slope):
     ac.check_symbolic_cs_ramp(cs_initial, cs_slope)
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["device_loop", "step_by_step"])
+@pytest.mark.parametrize("label", list(ac.STUDIES["studies"]))
+def test_legacy_study_runner_against_reference_report(label, fused):
+    # errors of the reference's run_convergence_studies (SuperLU solves) vs Jacobi to 1e-13
+    ac.check_run_convergence_studies(label, rel=1e-9, fused=fused)
