@@ -20,7 +20,7 @@ import math
 from abc import ABC, abstractmethod
 from collections import namedtuple
 from collections.abc import Mapping
-from typing import Callable, Dict, List, NamedTuple
+from typing import Callable, Dict, List, Literal, NamedTuple
 
 import numpy as np
 
@@ -572,6 +572,104 @@ class ForcingTermsFromDict(ForcingTermsBase):
 
     def fcs(self, t, xx, yy):
         return self._forcing_terms_dict["fcs"](t, xx, yy)
+
+
+# ------------------------------------------------------------------------------------------
+# Exact solutions given as plain Python callables, differentiated by second-order finite differences
+#                                                          reference src/prob1base.py:892-1155
+# ------------------------------------------------------------------------------------------
+TimeSteppingStrategy = Literal["forward", "center", "backward"]
+
+# one-dimensional second-order difference formulas as (offset in units of eps, weight) in the order
+# the terms are summed; first derivatives are divided by 2*eps, second derivatives by eps*eps
+_FD1 = {"center": ((1, 1.0), (-1, -1.0)),
+        "forward": ((0, -3.0), (1, 4.0), (2, -1.0)),
+        "backward": ((0, 3.0), (-1, -4.0), (-2, 1.0))}
+_FD2 = {"center": ((1, 1.0), (0, -2.0), (-1, 1.0)),
+        "forward": ((0, 2.0), (1, -5.0), (2, 4.0), (3, -1.0)),
+        "backward": ((0, 2.0), (-1, -5.0), (-2, 4.0), (-3, -1.0))}
+
+
+def pack_analytical_txy_with_o2fdm_derivatives(fn: Callable, *, default_eps: float = 1e-6,
+                                               time_stepping: str = "center") -> Callable:
+    """fn(t, x, y) -> g(t, x, y, *, d=(dt, dx, dy), op=None, small_eps=None): derivatives of total order
+    <= 2 and the Laplacian (op="lap" / "laplacian") by second-order differences of step eps; space
+    derivatives are centred, time derivatives follow `time_stepping`
+    (reference src/prob1base.py:895-1032)."""
+    if time_stepping not in _FD1:
+        raise ValueError("Invalid time stepping strategy")
+
+    def combine(terms, at):
+        acc = None
+        for off, w in terms:
+            v = w * at(off)
+            acc = v if acc is None else acc + v
+        return acc
+
+    def g(t, x, y, *, d=(0, 0, 0), op=None, small_eps=None):
+        eps = small_eps or default_eps
+        if op is not None:
+            if op.lower() not in ("laplacian", "lap"):
+                raise ValueError(f"Unknown operator: {op}. Use 'laplacian'/'lap'")
+            five = fn(t, x + eps, y) + fn(t, x - eps, y) + fn(t, x, y + eps) + fn(t, x, y - eps) - 4 * fn(t, x, y)
+            return five / (eps * eps)
+        nt, nx, ny = d
+        if any(n not in (0, 1, 2) for n in (nt, nx, ny)):
+            raise ValueError("Individual derivatives must be 0, 1, or 2")
+        if nt + nx + ny > 2:
+            raise ValueError("Combined derivative order must be 0, 1, or 2")
+        if nt:   # a time derivative wins over whatever else is asked, as in the reference
+            terms = (_FD1 if nt == 1 else _FD2)[time_stepping]
+            return combine(terms, lambda k: fn(t + k * eps, x, y)) / ((2 * eps) if nt == 1 else (eps * eps))
+        if nx == 1 and ny == 1:
+            cross = (fn(t, x + eps, y + eps) - fn(t, x + eps, y - eps) - fn(t, x - eps, y + eps)
+                     + fn(t, x - eps, y - eps))
+            return cross / (4 * eps * eps)
+        if nx:
+            terms = (_FD1 if nx == 1 else _FD2)["center"]
+            return combine(terms, lambda k: fn(t, x + k * eps, y)) / ((2 * eps) if nx == 1 else (eps * eps))
+        if ny:
+            terms = (_FD1 if ny == 1 else _FD2)["center"]
+            return combine(terms, lambda k: fn(t, x, y + k * eps)) / ((2 * eps) if ny == 1 else (eps * eps))
+        return fn(t, x, y)
+
+    return g
+
+
+class MMSCaseFromAnalytic(MMSCaseBase):
+    """Exact solution given as five callables f(t, xx, yy); the derivatives the forcing terms need come
+    from pack_analytical_txy_with_o2fdm_derivatives (reference src/prob1base.py:1036-1155).  Such a case
+    lives on the host by construction: with the ForcingTerms_* classes its forcing arrays are evaluated
+    there and streamed to the device at every time level."""
+
+    def __init__(self, model: DefaultModel01, *, grid: Grid, cp_base, T_base, cl_base, cd_base, cs_base):
+        super().__init__(grid, model)
+        self.cp_ex = pack_analytical_txy_with_o2fdm_derivatives(cp_base)
+        self.T_ex = pack_analytical_txy_with_o2fdm_derivatives(T_base)
+        self.cl_ex = pack_analytical_txy_with_o2fdm_derivatives(cl_base)
+        self.cd_ex = pack_analytical_txy_with_o2fdm_derivatives(cd_base)
+        self.cs_ex = pack_analytical_txy_with_o2fdm_derivatives(cs_base)
+
+
+def _add_analytic_accessors(cls):
+    orders = {"": (0, 0, 0), "dt_": (1, 0, 0), "dx_": (0, 1, 0), "dy_": (0, 0, 1)}
+    for var in _VIDX:
+        for prefix, d in orders.items():
+            def method(self, t, xx, yy, _v=var, _d=d):
+                g = getattr(self, _v + "_ex")
+                return g(t, xx, yy) if _d == (0, 0, 0) else g(t, xx, yy, d=_d)
+            method.__name__ = prefix + var
+            setattr(cls, prefix + var, method)
+        if var in ("T", "cl", "cd"):
+            def lap(self, t, xx, yy, _v=var):
+                g = getattr(self, _v + "_ex")
+                return g(t, xx, yy, d=(0, 2, 0)) + g(t, xx, yy, d=(0, 0, 2))
+            lap.__name__ = "lap_" + var
+            setattr(cls, "lap_" + var, lap)
+    return cls
+
+
+_add_analytic_accessors(MMSCaseFromAnalytic)
 
 
 # ------------------------------------------------------------------------------------------

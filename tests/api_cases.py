@@ -8,6 +8,7 @@ import os
 import numpy as np
 import pytest
 
+import analytic_fns
 import tedd.mms_trial_utils as mtu
 import tedd.prob1_mms_cases as p1mc
 import tedd.prob1base as p1
@@ -502,7 +503,8 @@ def check_symbolic_library_case_golden(cname, kname):
     g = lambda k: z[f"{cname}/{k}"]
     par = {k.split("/")[-1]: float(z[k]) for k in z.files if k.startswith(f"{cname}/param/")}
     ctor = {"stiff_exp_decay": p1mc.MMSCaseStiffExpDecay, "pol_oscillating": p1mc.MMSCasePolWithOscilatingTime,
-            "cs_zero_crossing": p1mc.MMSCaseCsZeroCrossing}[cname]
+            "cs_zero_crossing": p1mc.MMSCaseCsZeroCrossing,
+            "from_analytic": lambda grid, model: p1.MMSCaseFromAnalytic(model, grid=grid, **analytic_fns.BASES)}[cname]
     consts = dict(zip(p1.ModelConsts._fields, g("consts")))
     model = p1.DefaultModel02(p1.ModelConsts(**consts))
     grid = p1.Grid(g("x"), g("y"))

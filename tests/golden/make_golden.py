@@ -41,6 +41,9 @@ import prob1base as p1
 import prob1_mms_cases as p1mc
 import mms_trial_utils as mtu
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import analytic_fns  # noqa: E402  (tests/analytic_fns.py)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_ROOT = os.environ.get("TEDD_REFERENCE_ROOT", "/root/reference")
 
@@ -469,6 +472,8 @@ def symbolic_cases():
                             dict(ampl=0.7, speed=12.0), 0.0),
         # starts just before the sign change of cs at t = cs_A / cs_B = 0.5
         "cs_zero_crossing": (p1mc.MMSCaseCsZeroCrossing, {}, 0.49),
+        # plain callables differentiated by finite differences (MMSCaseFromAnalytic)
+        "from_analytic": (lambda grid, model: p1.MMSCaseFromAnalytic(model, grid=grid, **analytic_fns.BASES), {}, 0.1),
     }
 
 

@@ -90,7 +90,7 @@ def test_hcs_newton_residuals(case):
 
 
 @pytest.mark.parametrize("kname", ["reg", "cst", "hcs"])
-@pytest.mark.parametrize("cname", ac.SYMBOLIC_CASES)
+@pytest.mark.parametrize("cname", ac.SYMBOLIC_CASES + ["from_analytic"])
 def test_symbolic_library_case_golden(cname, kname):
     ac.check_symbolic_library_case_golden(cname, kname)
 
