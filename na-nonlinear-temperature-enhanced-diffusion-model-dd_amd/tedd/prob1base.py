@@ -1224,15 +1224,19 @@ class P_ModifiedEuler_C_Trapezoidal_TimeIntegratorBase(ABC):
         """Heun predictor for cs (reference src/prob1base.py:3174-3188, 3354-3374, 3631-3645)."""
         return self._substep_session(at_t, t, dt).ctx.predict_cp_cs(t, dt)[1]
 
-    def corrector_cp_step(self, T1, cl1, _cd1_ignored, *, at_t0, t0, dt):
-        """Closed-form trapezoidal corrector for cp (reference src/prob1base.py:2967-2996)."""
+    def corrector_cp_step(self, T1, cl1, _cd1_ignroed=None, *, at_t0, t0, dt, _cd1_ignored=None):
+        """Closed-form trapezoidal corrector for cp (reference src/prob1base.py:2967-2996).  The third
+        parameter keeps the reference's spelling, which its tests pass by keyword
+        (tests/test_isolated_correctors_cp_cs.py:107); the corrected spelling is accepted too."""
         assert dt > 0
         s = self._substep_session(at_t0, t0, dt)
-        cd1 = _cd1_ignored if _cd1_ignored is not None else at_t0.cd
+        cd1 = _cd1_ignroed if _cd1_ignroed is not None else _cd1_ignored
+        cd1 = cd1 if cd1 is not None else at_t0.cd
         return s.ctx.correct_cp_cs(t0, dt, T1, cl1, cd1, **self._cs_newton_args())[0]
 
     def corrector_cs_step(self, _T1_ignored, cl1, cd1, *, at_t0, t0, dt):
         """Corrector for cs (reference src/prob1base.py:3190-3219, 3376-3430, 3665-3702)."""
+        assert dt > 0
         s = self._substep_session(at_t0, t0, dt)
         T1 = _T1_ignored if _T1_ignored is not None else at_t0.T
         return s.ctx.correct_cp_cs(t0, dt, T1, cl1, cd1, **self._cs_newton_args())[1]

@@ -130,6 +130,71 @@ def check_reference_temporal_study(rel):
         assert summ.overall_combined_error == pytest.approx(row["overall"], rel=rel), row["dt"]
 
 
+ISOLATED = json.load(open(os.path.join(GOLDEN, "golden_isolated.json")))
+
+
+def _final_rate_at_least(errors, order=2.0, tol=0.1):
+    from tedd.cvg_studies_base import calculate_observed_rates
+    rate, status = calculate_observed_rates(errors, refinement_factor=2.0)[-1]
+    assert rate >= order - tol, (errors, rate, status)
+
+
+def check_isolated_operator_truncation(which):
+    """reference tests/test_spatial_isolated_T_accuracy.py:88-548: the field operators FT, Fcl, Fcd applied
+    to an exact state against the continuous right-hand side, with every unrelated model constant zero;
+    second order, and the error norms equal to those of the reference's operators."""
+    pytest.importorskip("sympy")
+    import isolated_cases
+    errors = isolated_cases.operator_truncation_errors(p1, which)
+    assert errors == pytest.approx(ISOLATED["operators"][which], rel=1e-7), which
+    _final_rate_at_least(errors)
+
+
+def check_coupled_subsystem_convergence(which):
+    """reference tests/test_spatial_isolated_T_accuracy.py:551-741: T-cl and T-cl-cd subsystems (cp = cs = 0,
+    several diffusivities and rate constants zero) through MMSTrial and the CsTriple predictor-corrector;
+    second order in space and the reference's own error norms.  Some of these norms are 1e-14 ... 1e-17
+    (one or two short steps from an exact state): the absolute tolerance is the rounding of the O(0.1)
+    fields."""
+    pytest.importorskip("sympy")
+    import isolated_cases
+    errors = isolated_cases.coupled_errors(p1, mtu, which)
+    for v, ref in ISOLATED["coupled"][which].items():
+        assert errors[v] == pytest.approx(ref, rel=1e-6, abs=5e-17), (which, v)
+        # the reference asserts the last rate of its own numbers; do the same where the mirrored
+        # numbers are the same numbers to the tolerance above
+        _final_rate_at_least(ref)
+        if min(ref) > 1e-13:
+            _final_rate_at_least(errors[v])
+    return errors
+
+
+def check_isolated_correctors_temporal_order():
+    """reference tests/test_isolated_correctors_cp_cs.py:53-142: the cp and cs correctors alone, fed the exact
+    T, cl, cd of the new time level (DefaultModel01, CsTriple, 30 x 30, dt = 2 / (10 * 2^k)); second order."""
+    model = p1.DefaultModel01(mc=p1.default_model_consts)   # the constants that test sets are the defaults
+    grid = p1.make_uniform_grid(30, 30)
+    case = p1mc.MMSCaseExpSin(grid=grid, model=model)
+    forcing = p1.ForcingTerms_CsTriple(mms_case=case, model=model)
+    field = p1.SemiDiscreteField_CsTriple(grid=grid, model=model, forcing_terms=forcing)
+    integ = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_CsTriple(semi_discrete_field=field, num_pc_steps=1,
+                                                                     num_newton_steps=1)
+    xx, yy = grid.xx, grid.yy
+    errors = {"cp": [], "cs": []}
+    for k in range(5):
+        dt = 2.0 / (10 * 2 ** k)
+        S0 = p1.StateVars(case.cp(0.0, xx, yy), case.T(0.0, xx, yy), case.cl(0.0, xx, yy), case.cd(0.0, xx, yy),
+                          case.cs(0.0, xx, yy), model=model, hh=grid.hh, kk=grid.kk)
+        T1, cl1, cd1 = case.T(dt, xx, yy), case.cl(dt, xx, yy), case.cd(dt, xx, yy)
+        cp1 = integ.corrector_cp_step(T1, cl1, _cd1_ignroed=None, at_t0=S0, t0=0.0, dt=dt)
+        cs1 = integ.corrector_cs_step(_T1_ignored=None, cl1=cl1, cd1=cd1, at_t0=S0, t0=0.0, dt=dt)
+        errors["cp"].append(grid.norm_H(cp1 - case.cp(dt, xx, yy)))
+        errors["cs"].append(grid.norm_H(cs1 - case.cs(dt, xx, yy)))
+    for v in ("cp", "cs"):
+        observed_rates_report(errors=errors[v], cmp_type="least", expected_rate=2.0, tolerance=0.1)
+    return errors
+
+
 STUDIES = json.load(open(os.path.join(GOLDEN, "golden_studies.json")))
 
 

@@ -22,6 +22,9 @@ The fixtures are plain data (inputs + the reference's outputs, float64 .npz and
                       (initial_*_pred, newton_step_*, corrector_*_step) for the three integrators
   golden_symbolic.npz forcing arrays and integrator steps for the three cases the reference states
                       symbolically only (StiffExpDecay, PolWithOscilatingTime, CsZeroCrossing)
+  golden_isolated.json truncation errors of FT / Fcl / Fcd on exact states and errors of the coupled T-cl and
+                      T-cl-cd subsystems, all with degenerate model constants
+  golden_statevars.npz the derived arrays of a StateVars on random fields (both model kinds)
   golden_studies.json the report of cvg_studies_base.run_convergence_studies (legacy study runner) for
                       two small CsTriple / HCsTriple studies
   golden_scalars.json MMSTrial.run_for_errors summaries (only with --scalars; slow)
@@ -43,6 +46,7 @@ import mms_trial_utils as mtu
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import analytic_fns  # noqa: E402  (tests/analytic_fns.py)
+import isolated_cases  # noqa: E402  (tests/isolated_cases.py)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_ROOT = os.environ.get("TEDD_REFERENCE_ROOT", "/root/reference")
@@ -517,6 +521,38 @@ def gen_symbolic():
 
 
 # ----------------------------------------------------------------------------------
+def gen_statevars():
+    """The 24 derived arrays of StateVars (face means, backward differences, Dl / V / Dd at the faces) on
+    seeded random fields over a non-uniform 8 x 6 node mesh, for both model kinds."""
+    rng = np.random.default_rng(20250503)
+    x, y = nonuniform_axis(7, 0.9, -0.1), nonuniform_axis(5, 0.8, 0.15)
+    grid = p1.Grid(x, y)
+    shape = grid.xx.shape
+    out = {"x": x, "y": y, "hh": grid.hh, "kk": grid.kk,
+           "cp": rng.random(shape) + 0.1, "T": rng.random(shape) * 100 + 273.15, "cl": rng.random(shape),
+           "cd": rng.random(shape), "cs": rng.random(shape), "consts": consts_vec("nb_a")}
+    out["T"][2, 3] = 0.0          # Dd := 0 where its temperature argument is 0 (model kind 1)
+    for kind in (1, 2):
+        S = p1.StateVars(out["cp"], out["T"], out["cl"], out["cd"], out["cs"], model=make_model("nb_a", kind),
+                         hh=grid.hh, kk=grid.kk)
+        for name in p1.StateVars._COMPUTED_PROPERTIES:
+            out[f"kind{kind}/{name}"] = np.asarray(getattr(S, name))
+    np.savez_compressed(os.path.join(HERE, "golden_statevars.npz"), **out)
+    print("golden_statevars.npz:", len(out), "arrays")
+
+
+# ----------------------------------------------------------------------------------
+def gen_isolated():
+    """Isolated-operator truncation errors and coupled-subsystem errors with degenerate model constants
+    (tests/isolated_cases.py run with the reference's modules)."""
+    out = {"operators": {w: isolated_cases.operator_truncation_errors(p1, w) for w in ("FT", "Fcl", "Fcd")},
+           "coupled": {w: isolated_cases.coupled_errors(p1, mtu, w) for w in ("T_cl", "T_cl_cd")}}
+    with open(os.path.join(HERE, "golden_isolated.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("golden_isolated.json written", out)
+
+
+# ----------------------------------------------------------------------------------
 def study_setups():
     return {
         "cstriple_pol": ("CsTriple", "pol", "nb_b"),
@@ -685,7 +721,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     np.seterr(all="ignore")
-    todo = a.only.split(",") if a.only else ["ops", "mms", "steps", "hcs", "substeps", "symbolic", "studies", "published"]
+    todo = a.only.split(",") if a.only else ["ops", "mms", "steps", "hcs", "substeps", "symbolic", "studies", "isolated", "statevars", "published"]
     if "ops" in todo:
         gen_ops()
     if "mms" in todo:
@@ -700,6 +736,10 @@ if __name__ == "__main__":
         gen_symbolic()
     if "studies" in todo:
         gen_studies()
+    if "isolated" in todo:
+        gen_isolated()
+    if "statevars" in todo:
+        gen_statevars()
     if "published" in todo:
         gen_published()
     if a.scalars:

@@ -117,3 +117,17 @@ def test_symbolic_cs_ramp_single_step(cs_initial, cs_slope):
 @pytest.mark.parametrize("label", list(ac.STUDIES["studies"]))
 def test_legacy_study_runner_against_reference_report(label, fused):
     ac.check_run_convergence_studies(label, rel=1e-9, fused=fused)
+
+
+@pytest.mark.parametrize("which", ["FT", "Fcl", "Fcd"])
+def test_isolated_operator_truncation_order(which):
+    ac.check_isolated_operator_truncation(which)
+
+
+@pytest.mark.parametrize("which", ["T_cl", "T_cl_cd"])
+def test_coupled_subsystem_spatial_convergence(which):
+    ac.check_coupled_subsystem_convergence(which)
+
+
+def test_isolated_correctors_temporal_order():
+    ac.check_isolated_correctors_temporal_order()

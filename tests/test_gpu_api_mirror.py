@@ -134,3 +134,17 @@ def test_symbolic_cs_ramp_single_step(cs_initial, cs_slope):
 def test_legacy_study_runner_against_reference_report(label, fused):
     # errors of the reference's run_convergence_studies (SuperLU solves) vs Jacobi to 1e-13
     ac.check_run_convergence_studies(label, rel=1e-9, fused=fused)
+
+
+@pytest.mark.parametrize("which", ["FT", "Fcl", "Fcd"])
+def test_isolated_operator_truncation_order(which):
+    ac.check_isolated_operator_truncation(which)
+
+
+@pytest.mark.parametrize("which", ["T_cl", "T_cl_cd"])
+def test_coupled_subsystem_spatial_convergence(which):
+    ac.check_coupled_subsystem_convergence(which)
+
+
+def test_isolated_correctors_temporal_order():
+    ac.check_isolated_correctors_temporal_order()
