@@ -449,6 +449,48 @@ def _same_nodes(grid: Grid, xx, yy):
             and np.array_equal(xx[:, -1], grid.x) and np.array_equal(yy[-1, :], grid.y))
 
 
+class _MeshSessions:
+    """Device sessions of an object that is asked to evaluate at node coordinates (xx, yy): its own grid,
+    or any other tensor-product mesh handed in as meshgrid arrays (the reference's cases and forcing terms
+    are plain functions of the coordinates, e.g. a case built on one grid and evaluated on a family of
+    refined grids).  A few foreign meshes are kept, the least recently used dropped."""
+
+    KEEP = 4
+
+    def __init__(self):
+        self._foreign = {}    # bytes of the axes -> [Grid, session or None]
+
+    def grid_for(self, own: Grid, xx, yy):
+        if _same_nodes(own, xx, yy):
+            return own
+        xx, yy = np.asarray(xx, dtype=float), np.asarray(yy, dtype=float)
+        if not (xx.ndim == 2 and xx.shape == yy.shape and xx.shape[0] >= 3 and xx.shape[1] >= 3
+                and np.array_equal(xx, np.broadcast_to(xx[:, :1], xx.shape))
+                and np.array_equal(yy, np.broadcast_to(yy[:1, :], yy.shape))
+                and np.all(np.diff(xx[:, 0]) > 0) and np.all(np.diff(yy[0, :]) > 0)):
+            raise NotImplementedError("the device library evaluates at the nodes of a tensor-product mesh "
+                                      "(meshgrid arrays of increasing axes with at least 3 nodes each)")
+        key = xx[:, 0].tobytes() + b"|" + yy[0, :].tobytes()
+        entry = self._foreign.pop(key, None)
+        if entry is None:
+            entry = [Grid(xx[:, 0].copy(), yy[0, :].copy()), None]
+            while len(self._foreign) >= self.KEEP:
+                self._foreign.pop(next(iter(self._foreign)))
+        self._foreign[key] = entry     # most recently used last
+        return entry[0]
+
+    def session(self, own: Grid, grid: Grid, own_session, make):
+        """The session on `grid`; `own_session` is the caller's session on its own grid (or None)."""
+        if grid is own:
+            return own_session if own_session is not None else make(grid)
+        for entry in self._foreign.values():
+            if entry[0] is grid:
+                if entry[1] is None:
+                    entry[1] = make(grid)
+                return entry[1]
+        return make(grid)
+
+
 # ------------------------------------------------------------------------------------------
 # MMS cases and forcing terms          reference src/prob1base.py:714-889, 2296-2425, 3468-3551
 # ------------------------------------------------------------------------------------------
@@ -479,25 +521,30 @@ class MMSCaseDevice(MMSCaseBase):
     def __init__(self, grid: Grid, model: DefaultModel01):
         super().__init__(grid, model)
         self._session = None
+        self._meshes = _MeshSessions()
         self._memo = {}
 
     def mms_params(self):
         return ()
 
-    def _device(self):
-        if self._session is None:
-            self._session = _Session(self._grid, self._model, _ffi.REACT_REGHCSTRIPLE, 0.0,
-                                     self.mms_case_id, self.mms_params())
-        self._session.refresh(self._model, 0.0, self.mms_params())
-        return self._session
+    def _make_session(self, grid):
+        return _Session(grid, self._model, _ffi.REACT_REGHCSTRIPLE, 0.0, self.mms_case_id, self.mms_params())
+
+    def _device(self, grid=None):
+        grid = self._grid if grid is None else grid
+        s = self._meshes.session(self._grid, grid, self._session, self._make_session)
+        if grid is self._grid:
+            self._session = s
+        s.refresh(self._model, 0.0, self.mms_params())
+        return s
 
     def _eval(self, what, t, xx, yy):
-        if not _same_nodes(self._grid, xx, yy):
-            raise NotImplementedError("the device MMS cases are evaluated at the nodes of their own grid")
-        key = (what, float(t), tuple(self._model.consts_vector()))
+        grid = self._meshes.grid_for(self._grid, xx, yy)
+        key = (what, float(t), tuple(self._model.consts_vector()), id(grid))
         if key not in self._memo:
             self._memo.clear()
-            self._memo[key] = self._device().ctx.eval_mms(t, what)
+            self._memo[key] = self._device(grid).ctx.eval_mms(t, what)
+            self._memo["grid"] = grid      # keeps id(grid) unambiguous while the entry lives
         return self._memo[key]
 
     def exact_fields(self, t):
@@ -786,7 +833,10 @@ class _HostForcingTerms(ForcingTermsBase):
         return c.dt_cp(t, xx, yy) + cp * (m.K1 * (1.0 + c.cl(t, xx, yy)) + m.K2 * c.T(t, xx, yy))
 
     def fcp(self, t, xx=None, yy=None):
-        return avg_int(lambda p, q: self.fcp_ptwise(t, p, q), self.grid)
+        """Cell averages over the mesh of the coordinates handed in (reference src/prob1base.py:2325-2328:
+        avg_int on Grid(xx, yy)); the case's own grid when none are given."""
+        grid = self.grid if xx is None or _same_nodes(self.grid, xx, yy) else Grid(xx, yy)
+        return avg_int(lambda p, q: self.fcp_ptwise(t, p, q), grid)
 
     def fT(self, t, xx, yy):
         c, m = self._mms_case, self._model
@@ -830,6 +880,7 @@ class _DeviceForcingTerms(ForcingTermsBase):
         self._model = model
         self._eta = float(eta)
         self._session = None
+        self._meshes = _MeshSessions()
         self._memo = {}
 
     @property
@@ -850,25 +901,28 @@ class _DeviceForcingTerms(ForcingTermsBase):
             xx, yy = (g.xx, g.yy) if xx is None else (xx, yy)
             key = ("host", float(t))
             if key not in self._memo or not _same_nodes(g, xx, yy):
-                vals = [self._host.fcp(t), self._host.fT(t, xx, yy), self._host.fcl(t, xx, yy),
+                vals = [self._host.fcp(t, xx, yy), self._host.fT(t, xx, yy), self._host.fcl(t, xx, yy),
                         self._host.fcd(t, xx, yy), self._host.fcs(t, xx, yy)]
                 if not _same_nodes(g, xx, yy):
                     return vals
                 self._memo.clear()
                 self._memo[key] = vals
             return self._memo[key]
-        if not _same_nodes(self.grid, xx, yy):
-            raise NotImplementedError("device forcing terms are evaluated at the nodes of their own grid")
-        if self._session is None:
-            self._session = _Session(self.grid, self._model, self.reaction_kind, self._eta,
-                                     self._mms_case.mms_case_id, self._mms_case.mms_params(),
-                                     program=getattr(self._mms_case, "_program", None))
-        self._session.refresh(self._model, self._eta, self._mms_case.mms_params())
-        key = (float(t), self._session._sent)
+        grid = self._meshes.grid_for(self.grid, xx, yy)
+        s = self._meshes.session(self.grid, grid, self._session, self._make_session)
+        if grid is self.grid:
+            self._session = s
+        s.refresh(self._model, self._eta, self._mms_case.mms_params())
+        key = (float(t), s._sent, id(grid))
         if key not in self._memo:
             self._memo.clear()
-            self._memo[key] = self._session.ctx.eval_forcing(t)
+            self._memo[key] = s.ctx.eval_forcing(t)
+            self._memo["grid"] = grid      # keeps id(grid) unambiguous while the entry lives
         return self._memo[key]
+
+    def _make_session(self, grid):
+        return _Session(grid, self._model, self.reaction_kind, self._eta, self._mms_case.mms_case_id,
+                        self._mms_case.mms_params(), program=getattr(self._mms_case, "_program", None))
 
     def fcp(self, t, xx=None, yy=None):
         return self._eval(t, xx, yy)[0].copy()
@@ -981,7 +1035,9 @@ class _DeviceField(SemiDiscreteFieldBase):
             return None
         if ft._host is not None:  # no closed form in the library: host-evaluated, streamed
             return None
-        if ft.grid is not self._grid or ft.model is not self._model:
+        # (the grid the case was built with does not matter: a closed form is a function of the coordinates,
+        # and the reference hands the field's own node coordinates to the forcing callables)
+        if ft.model is not self._model:
             return None
         if self.reaction_kind == _ffi.REACT_REGHCSTRIPLE and float(ft._eta) != self._eta_now():
             return None

@@ -169,6 +169,119 @@ def check_coupled_subsystem_convergence(which):
     return errors
 
 
+def check_foreign_mesh_evaluation():
+    """A case / forcing-terms object built on one grid and asked for values at the nodes of other
+    tensor-product meshes (the reference's objects are plain functions of the coordinates; its tests build the
+    case once and refine the mesh: tests/test_reghcstriple.py:277-336)."""
+    model = model_of("nb_a")
+    home = p1.make_uniform_grid(N=6, M=5)
+    case = p1mc.MMSCaseExpSin(grid=home, model=model)
+    forcing = p1.ForcingTerms_RegHCsTriple(mms_case=case, model=model, regularization_factor=ETA)
+    x = np.array([0.0, 0.1, 0.35, 0.5, 0.8, 1.0])
+    for other in (p1.make_uniform_grid(N=9, M=7), p1.Grid(x, x[:4] / 0.5), p1.make_uniform_grid(N=3, M=4),
+                  p1.make_uniform_grid(N=11, M=3), p1.make_uniform_grid(N=4, M=12), p1.make_uniform_grid(N=9, M=7)):
+        there = p1mc.MMSCaseExpSin(grid=other, model=model)
+        forcing_there = p1.ForcingTerms_RegHCsTriple(mms_case=there, model=model, regularization_factor=ETA)
+        for name in ("cp", "T", "cl", "cd", "cs", "dt_cs", "dx_T", "dy_cl", "lap_cd"):
+            np.testing.assert_array_equal(getattr(case, name)(0.3, other.xx, other.yy), getattr(there, name)(0.3, other.xx, other.yy))
+        for name in ("fcp", "fT", "fcl", "fcd", "fcs"):
+            np.testing.assert_array_equal(getattr(forcing, name)(0.3, other.xx, other.yy),
+                                          getattr(forcing_there, name)(0.3, other.xx, other.yy))
+        # and the object still answers on its own grid
+        assert case.T(0.3, home.xx, home.yy).shape == home.xx.shape
+        assert forcing.fT(0.3, home.xx, home.yy).shape == home.xx.shape
+    # a field on another grid than its forcing terms' case steps like one whose case shares its grid
+    grid = p1.make_uniform_grid(N=8, M=8)
+    steps = []
+    for case_grid in (home, grid):
+        c = p1mc.MMSCaseExpSin(grid=case_grid, model=model)
+        f = p1.ForcingTerms_RegHCsTriple(mms_case=c, model=model, regularization_factor=ETA)
+        field = p1.SemiDiscreteField_RegHCsTriple(grid=grid, model=model, forcing_terms=f, regularization_factor=ETA)
+        integ = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple(field, regularization_factor=ETA)
+        S = integ.step(p1.state_from_mms_when(mms_case=c, t=0.0, grid=grid), t0=0.0, dt=1e-3)
+        steps.append(S)
+    for v in ("cp", "T", "cl", "cd", "cs"):
+        np.testing.assert_array_equal(getattr(steps[0], v), getattr(steps[1], v))
+    # scattered points are not a mesh
+    with pytest.raises(NotImplementedError):
+        case.T(0.3, np.random.default_rng(0).random((4, 4)), np.random.default_rng(1).random((4, 4)))
+    # a host-evaluated case: cell averages follow the mesh handed in
+    if p1mc.sympy is not None:
+        t, x, y = p1.t_sym, p1.x_sym, p1.y_sym
+        ex = dict(cp_sym_expr=1 + x * y * t, T_sym_expr=p1mc.sympy.sin(x + t) * y, cl_sym_expr=x ** 2 + y,
+                  cd_sym_expr=1 + t * y, cs_sym_expr=1 - t + x, device_program=False)
+        sym = p1.MMSCaseSymbolic(grid=home, model=model, **ex)
+        sym_there = p1.MMSCaseSymbolic(grid=grid, model=model, **ex)
+        a = p1.ForcingTerms_CsTriple(mms_case=sym, model=model).fcp(0.2, grid.xx, grid.yy)
+        b = p1.ForcingTerms_CsTriple(mms_case=sym_there, model=model).fcp(0.2, grid.xx, grid.yy)
+        np.testing.assert_array_equal(a, b)
+
+
+REGHCS = json.load(open(os.path.join(GOLDEN, "golden_reghcs.json")))
+
+
+def check_reghcs_scenarios(eta):
+    """reference tests/test_reghcstriple.py:109-577 for one regularisation factor, with the reference's own
+    numbers (tests/golden/make_golden.py --only reghcs) beside its assertions."""
+    import reghcs_cases as rc
+    ref = REGHCS[str(eta)]
+    close = lambda a, b, rel=1e-9, abs_=1e-15: a == pytest.approx(b, rel=rel, abs=abs_)
+    # the regularised Heaviside function: bounded, monotone limits, steeper than a factor of 5
+    h = np.array(rc.heaviside_values(p1, eta))
+    assert close(list(h), ref["heaviside"], rel=1e-14)
+    assert np.all(h >= 0) and np.all(h <= 1) and h[0] < 0.01 and h[-1] > 0.99 and 0.45 < h[50] < 0.55
+    assert h[51] > p1.heaviside_regularized(np.linspace(-5, 5, 101), 5.0)[51]
+    # the field applied to the exact solution approximates the time derivative
+    for N in rc.SIZES:
+        mine = rc.field_vs_time_derivative(p1, p1mc, N, eta)
+        for v, val in ref["field_vs_dt"][str(N)].items():
+            assert close(mine[v], val, rel=1e-8), (N, v)
+            assert N < 32 or mine[v] < 1e-2
+    errs = rc.FT_refinement_errors(p1, p1mc, eta)
+    assert close(errs, ref["FT_refinement"], rel=1e-8)
+    observed_rates_report(errs, expected_rate=2.0, tolerance=0.3, cmp_type="least", halt_print=True)
+    # one step of each integrator from the exact state
+    for key, val in ref["fe_one_step"].items():
+        N, dt = key.split("/")
+        mine = rc.one_step_errors(p1, p1mc, int(N), eta, "fe", float(dt))
+        assert all(close(mine[v], val[v], rel=1e-8) for v in val), key
+    for N, val in ref["pc_one_step"].items():
+        mine = rc.one_step_errors(p1, p1mc, int(N), eta, "pc", 1e-3)
+        assert all(close(mine[v], val[v], rel=1e-6) for v in val), (N, mine, val)
+        assert int(N) < 32 or max(mine.values()) < 1e-2
+    errs = rc.forward_euler_temporal_errors(p1, p1mc, eta)
+    assert close(errs, ref["fe_temporal"], rel=1e-8)
+    observed_rates_report(errs, expected_rate=1.0, tolerance=0.15, cmp_type="equal", halt_print=True)
+    mine = rc.short_trials(p1, p1mc, mtu, eta)
+    for k in ("fe", "pc"):
+        assert close(mine[k], ref["short_trials"][k], rel=1e-8), k
+        assert mine[k] < 1e-1
+
+
+def check_gradient_T_one_step():
+    """reference tests/test_spatial_h1_isolated_T_accuracy.py:57-173: error of the discrete gradient of T after
+    one step, forcing given as a dictionary of callables (fT of the forcing-terms class, zeros otherwise:
+    the field then streams host-evaluated arrays); the reference's numbers, and its order assertion."""
+    pytest.importorskip("sympy")
+    import isolated_cases
+    errors = isolated_cases.gradient_T_one_step_errors(p1)
+    assert errors == pytest.approx(ISOLATED["gradient_T_one_step"], rel=1e-6, abs=1e-16)
+    _final_rate_at_least(errors)
+
+
+def check_forward_euler_T_cl():
+    """reference tests/test_feuler_spatial_accuracy.py:57-186: forward Euler on the coupled T-cl subsystem
+    (DefaultModel01, every constant of the other equations zero)."""
+    pytest.importorskip("sympy")
+    import isolated_cases
+    from tedd.cvg_studies_base import RateStatus, calculate_observed_rates
+    errors = isolated_cases.forward_euler_T_cl_errors(p1)
+    for v, ref in ISOLATED["forward_euler_T_cl"].items():
+        assert errors[v] == pytest.approx(ref, rel=1e-6, abs=1e-16), v
+        rate, status = calculate_observed_rates(errors[v], refinement_factor=2.0)[-1]
+        assert status == RateStatus.OK and rate == pytest.approx(2.0, abs=0.2), (v, rate, status)
+
+
 def check_isolated_correctors_temporal_order():
     """reference tests/test_isolated_correctors_cp_cs.py:53-142: the cp and cs correctors alone, fed the exact
     T, cl, cd of the new time level (DefaultModel01, CsTriple, 30 x 30, dt = 2 / (10 * 2^k)); second order."""

@@ -24,6 +24,8 @@ The fixtures are plain data (inputs + the reference's outputs, float64 .npz and
                       symbolically only (StiffExpDecay, PolWithOscilatingTime, CsZeroCrossing)
   golden_isolated.json truncation errors of FT / Fcl / Fcd on exact states and errors of the coupled T-cl and
                       T-cl-cd subsystems, all with degenerate model constants
+  golden_reghcs.json  RegHCsTriple scenarios for three regularisation factors: Heaviside values, field vs time
+                      derivative, one-step errors, forward-Euler temporal errors, short MMSTrial runs
   golden_statevars.npz the derived arrays of a StateVars on random fields (both model kinds)
   golden_studies.json the report of cvg_studies_base.run_convergence_studies (legacy study runner) for
                       two small CsTriple / HCsTriple studies
@@ -47,6 +49,7 @@ import mms_trial_utils as mtu
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import analytic_fns  # noqa: E402  (tests/analytic_fns.py)
 import isolated_cases  # noqa: E402  (tests/isolated_cases.py)
+import reghcs_cases  # noqa: E402  (tests/reghcs_cases.py)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_ROOT = os.environ.get("TEDD_REFERENCE_ROOT", "/root/reference")
@@ -521,6 +524,15 @@ def gen_symbolic():
 
 
 # ----------------------------------------------------------------------------------
+def gen_reghcs():
+    """tests/reghcs_cases.py run with the reference's modules."""
+    out = reghcs_cases.everything(p1, p1mc, mtu)
+    with open(os.path.join(HERE, "golden_reghcs.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("golden_reghcs.json written")
+
+
+# ----------------------------------------------------------------------------------
 def gen_statevars():
     """The 24 derived arrays of StateVars (face means, backward differences, Dl / V / Dd at the faces) on
     seeded random fields over a non-uniform 8 x 6 node mesh, for both model kinds."""
@@ -546,7 +558,9 @@ def gen_isolated():
     """Isolated-operator truncation errors and coupled-subsystem errors with degenerate model constants
     (tests/isolated_cases.py run with the reference's modules)."""
     out = {"operators": {w: isolated_cases.operator_truncation_errors(p1, w) for w in ("FT", "Fcl", "Fcd")},
-           "coupled": {w: isolated_cases.coupled_errors(p1, mtu, w) for w in ("T_cl", "T_cl_cd")}}
+           "coupled": {w: isolated_cases.coupled_errors(p1, mtu, w) for w in ("T_cl", "T_cl_cd")},
+           "gradient_T_one_step": isolated_cases.gradient_T_one_step_errors(p1),
+           "forward_euler_T_cl": isolated_cases.forward_euler_T_cl_errors(p1)}
     with open(os.path.join(HERE, "golden_isolated.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("golden_isolated.json written", out)
@@ -721,7 +735,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     np.seterr(all="ignore")
-    todo = a.only.split(",") if a.only else ["ops", "mms", "steps", "hcs", "substeps", "symbolic", "studies", "isolated", "statevars", "published"]
+    todo = a.only.split(",") if a.only else ["ops", "mms", "steps", "hcs", "substeps", "symbolic", "studies", "isolated", "statevars", "reghcs", "published"]
     if "ops" in todo:
         gen_ops()
     if "mms" in todo:
@@ -740,6 +754,8 @@ if __name__ == "__main__":
         gen_isolated()
     if "statevars" in todo:
         gen_statevars()
+    if "reghcs" in todo:
+        gen_reghcs()
     if "published" in todo:
         gen_published()
     if a.scalars:

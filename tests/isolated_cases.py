@@ -118,3 +118,62 @@ def coupled_errors(p1, mtu, which, N_list=(16, 32, 64, 128), Tf=1e-4, dt_const=1
         for v in variables:
             out[v].append(float(summary.per_variable_sup_errors[v]))
     return out
+
+
+def gradient_T_one_step_errors(p1, N_list=(8, 16, 32, 64), dt_const=0.1):
+    """p-norm of the error of grad_H(T) after one predictor-corrector step of dt = dt_const h^2, heat equation
+    only (DT the one non-zero constant); the field gets a dictionary of forcing callables: fT of the
+    CsTriple forcing terms, zeros for the rest
+    (the scenario of reference tests/test_spatial_h1_isolated_T_accuracy.py:57-173)."""
+    t, x, y, pi = _sym(p1)
+    model = make_model(p1, DT=1e-3)
+    zero = sympy.S(0)
+    T = sympy.sin(pi * x) * sympy.sin(pi * y) * sympy.exp(-t)
+    out = []
+    for N in N_list:
+        dt = dt_const / N ** 2
+        grid = p1.make_uniform_grid(N, N)
+        case = p1.MMSCaseSymbolic(grid=grid, model=model, cp_sym_expr=zero, T_sym_expr=T, cl_sym_expr=zero,
+                                  cd_sym_expr=zero, cs_sym_expr=zero, t_var=t, x_var=x, y_var=y)
+        full = p1.ForcingTerms_CsTriple(model=model, mms_case=case)
+        nothing = lambda t_, xx, yy, g=grid: g.make_full0()
+        forcing = p1.ForcingTermsFromDict({"fcp": nothing, "fT": full.fT, "fcl": nothing, "fcd": nothing, "fcs": nothing})
+        field = p1.SemiDiscreteField_CsTriple(grid=grid, model=model, forcing_terms=forcing)
+        integ = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_CsTriple(semi_discrete_field=field, num_pc_steps=1,
+                                                                         num_newton_steps=1)
+        S0 = p1.state_from_mms_when(mms_case=case, t=0.0, grid=grid)
+        S1 = integ.step(S0, t0=0.0, dt=dt)
+        gx, gy = grid.grad_H(S1.T)
+        ex, ey = grid.grad_H(case.T(dt, grid.xx, grid.yy))
+        out.append(float(grid.norm_p(gx - ex, gy - ey)))
+    return out
+
+
+def forward_euler_T_cl_errors(p1, N_list=(8, 16, 32, 64), Tf=1e-3, cfl=0.1):
+    """{T, cl: H-norm errors at Tf} of forward Euler on the coupled T-cl subsystem (DefaultModel01, cp = cd =
+    cs = 0) with dt = cfl h^2 / max(DT, Dl), adjusted to end at Tf
+    (the scenario of reference tests/test_feuler_spatial_accuracy.py:57-186)."""
+    import math
+    t, x, y, pi = _sym(p1)
+    zero = sympy.S(0)
+    consts = dict(ZERO, K3=1e-3, K4=5e-3, DT=1e-3, Dl_max=8.0e-4, gamma_T=1e-9)
+    model = p1.DefaultModel01(p1.ModelConsts(R0=p1.R0, Ea=p1.Ea, **consts))
+    T = 10 * sympy.sin(pi * x) * sympy.sin(pi * y) * (1 + t)
+    cl = (sympy.cos(pi * x) ** 2 - 1) * (1 - sympy.cos(pi * y) ** 2) * t
+    out = {"T": [], "cl": []}
+    for N in N_list:
+        grid = p1.make_uniform_grid(N, N)
+        case = p1.MMSCaseSymbolic(grid=grid, model=model, cp_sym_expr=zero, T_sym_expr=T, cl_sym_expr=cl,
+                                  cd_sym_expr=zero, cs_sym_expr=zero, t_var=t, x_var=x, y_var=y)
+        forcing = p1.ForcingTerms_CsTriple(mms_case=case, model=model)
+        field = p1.SemiDiscreteField_CsTriple(grid=grid, model=model, forcing_terms=forcing)
+        integ = p1.ForwardEulerIntegrator(semi_discrete_field=field)
+        steps = math.ceil(Tf / (cfl / N ** 2 / max(model.DT, float(model.Dl(0.0)))))
+        dt = Tf / steps
+        S, now = p1.state_from_mms_when(mms_case=case, t=0.0, grid=grid), 0.0
+        for _ in range(steps):
+            S = integ.step(S, t0=now, dt=dt)
+            now += dt
+        for v in out:
+            out[v].append(float(grid.norm_H(getattr(S, v) - getattr(case, v)(Tf, grid.xx, grid.yy))))
+    return out

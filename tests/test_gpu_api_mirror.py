@@ -148,3 +148,20 @@ def test_coupled_subsystem_spatial_convergence(which):
 
 def test_isolated_correctors_temporal_order():
     ac.check_isolated_correctors_temporal_order()
+
+
+def test_gradient_T_one_step_spatial_order():
+    ac.check_gradient_T_one_step()
+
+
+def test_forward_euler_T_cl_spatial_order():
+    ac.check_forward_euler_T_cl()
+
+
+@pytest.mark.parametrize("eta", [10.0, 50.0, 100.0])
+def test_reghcs_scenarios_against_reference_numbers(eta):
+    ac.check_reghcs_scenarios(eta)
+
+
+def test_cases_and_forcing_terms_evaluate_on_foreign_meshes():
+    ac.check_foreign_mesh_evaluation()
