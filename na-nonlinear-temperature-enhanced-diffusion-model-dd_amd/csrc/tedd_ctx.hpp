@@ -1347,7 +1347,7 @@ public:
     void raise_corrector_flag(int flag) {
         if (flag == 0) return;
         be.memset0(d_ints + 1, sizeof(int));
-        throw InvalidError("Denominator 2 - dt Kd (Sd - Cd1) (1 + Cl1) below positiveness treshold.");
+        throw InvalidError("Denominator 2 - \xce\x94t Kd (Sd - Cd1) (1 + Cl1) below positiveness treshold.");  // UTF-8 Delta, the reference's text
     }
 
     // ------------------------------------------------------------------ multi-step with fused norms

@@ -1119,6 +1119,60 @@ class _DeviceField(SemiDiscreteFieldBase):
     def delcd_ab_Fcd_ij(self, state, *, a, b):
         return self._jac(5, state, a, b)
 
+    # ---- the Cs/Cd interaction law, stated for callers that inspect it ------------------------------
+    # [Cs-Cd-int] = F1(cp) (a_T T + b_T) (a_cl cl + b_cl) (a_cd cd + b_cd) F2(cs) with null boundary values
+    # (reference src/prob1base.py:2440-2597; the three families: :2863-2876, :3320-3337, :3580-3593).  These
+    # NumPy accessors describe the law the device kernels have built in for the field's reaction kind; the
+    # kernels do not call them, so overriding one in a subclass does not change a step.
+    def cscd_reaction_T(self):
+        return (0, 1)
+
+    def cscd_reaction_cl(self):
+        return (1, 1)
+
+    def cscd_reaction_cd(self):
+        return (-1, self.model.Sd)
+
+    def cscd_reaction_cp(self, cp):
+        return self.grid.const_with_nullbd(1)
+
+    def cscd_reaction_cs(self, cs):
+        cs = np.asarray(cs, dtype=float)
+        if self.reaction_kind == _ffi.REACT_REGHCSTRIPLE:
+            return self.model.Kd * heaviside_regularized(cs, self._eta_now())
+        if self.reaction_kind == _ffi.REACT_HCSTRIPLE:
+            return self.model.Kd * (cs > 0)
+        return self.model.Kd * cs
+
+    def _cscd_product(self, state, slope_of=None):
+        """The interaction term, or its derivative with respect to the nodal value of `slope_of`."""
+        out = self.cscd_reaction_cp(state.cp) * self.cscd_reaction_cs(state.cs)
+        for name, (slope, offset) in (("T", self.cscd_reaction_T()), ("cl", self.cscd_reaction_cl()),
+                                      ("cd", self.cscd_reaction_cd())):
+            if name == slope_of:
+                if slope == 0.0:
+                    return self.grid.make_full0()
+                out = out * slope
+            else:
+                out = out * (slope * getattr(state, name) + offset)
+        return out * self.grid.null_bd_mask
+
+    def cscd_reaction_term(self, state: StateVars):
+        return self._cscd_product(state)
+
+    def _del_cscd(self, state, name, a, b):
+        assert a in (-1, 0, 1) and b in (-1, 0, 1) and (a == 0 or b == 0)
+        return self._cscd_product(state, slope_of=name) if a == 0 and b == 0 else self.grid.make_full0()
+
+    def delT_ab_cscd_reaction_ij(self, state: StateVars, *, a, b):
+        return self._del_cscd(state, "T", a, b)
+
+    def delcl_ab_cscd_reaction_ij(self, state: StateVars, *, a, b):
+        return self._del_cscd(state, "cl", a, b)
+
+    def delcd_ab_cscd_reaction_ij(self, state: StateVars, *, a, b):
+        return self._del_cscd(state, "cd", a, b)
+
 
 class SemiDiscreteField_CsTriple(_DeviceField):
     """[Cs-Cd-int] = Kd (Sd - Cd)(1 + Cl) Cs   (reference src/prob1base.py:2842-2876)."""

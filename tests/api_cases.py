@@ -217,6 +217,50 @@ def check_foreign_mesh_evaluation():
         np.testing.assert_array_equal(a, b)
 
 
+def check_interaction_law_accessors(kind):
+    """reference tests/test_semidiscrete_field_hcs_triple.py:118-542 (and the same law for the other two
+    families): the accessors of the Cs/Cd interaction against their closed form, and against what the device
+    operators do with it: Fcs = -[Cs-Cd-int] and, on constant fields (no diffusion), Fcd = +[Cs-Cd-int]."""
+    model = model_of("stress")
+    grid = p1.make_uniform_grid(N=4, M=5)
+    common = {"regularization_factor": 7.0} if kind == "reg" else {}
+    field_cls = {"reg": p1.SemiDiscreteField_RegHCsTriple, "cs3": p1.SemiDiscreteField_CsTriple,
+                 "hcs": p1.SemiDiscreteField_HCsTriple}[kind]
+    field = field_cls(grid=grid, model=model, forcing_terms=p1.NoForcingTerms(grid=grid), **common)
+    gain = {"reg": lambda c: p1.heaviside_regularized(c, 7.0), "cs3": lambda c: c, "hcs": lambda c: float(c > 0)}[kind]
+    assert field.cscd_reaction_T() == (0, 1) and field.cscd_reaction_cl() == (1, 1)
+    assert field.cscd_reaction_cd() == (-1, model.Sd)
+    np.testing.assert_array_equal(field.cscd_reaction_cp(np.zeros(grid.full_shape)), grid.null_bd_mask)
+    cp, T, cl, cd = 0.1, 0.2, 0.3, 0.4
+    for cs in (2.0, 1e-10, 0.0, -1e-10, -2.0):
+        full = lambda v: np.full(grid.full_shape, v, dtype=float)
+        np.testing.assert_allclose(field.cscd_reaction_cs(full(cs)), full(model.Kd * gain(cs)), rtol=1e-14)
+        S = p1.StateVars(full(cp), full(T), full(cl), full(cd), full(cs), model=model, hh=grid.hh, kk=grid.kk)
+        expected = model.Kd * gain(cs) * (1 + cl) * (model.Sd - cd) * grid.null_bd_mask
+        term = field.cscd_reaction_term(S)
+        np.testing.assert_allclose(term, expected, rtol=1e-13, atol=0)
+        np.testing.assert_allclose(field.Fcs(S, 0.0), -expected, rtol=1e-13, atol=1e-300)
+        np.testing.assert_allclose(field.Fcd(S, 0.0), expected, rtol=1e-12, atol=1e-22)
+        np.testing.assert_array_equal(field.delT_ab_cscd_reaction_ij(S, a=0, b=0), 0.0)     # a_T = 0
+        np.testing.assert_allclose(field.delcl_ab_cscd_reaction_ij(S, a=0, b=0),
+                                   model.Kd * gain(cs) * (model.Sd - cd) * grid.null_bd_mask, rtol=1e-13)
+        np.testing.assert_allclose(field.delcd_ab_cscd_reaction_ij(S, a=0, b=0),
+                                   -model.Kd * gain(cs) * (1 + cl) * grid.null_bd_mask, rtol=1e-13)
+        # the reaction enters the diagonal of d Fcd / d cd (constant fields: the diffusion part is the
+        # discrete Laplacian's diagonal, the same for every value of cs)
+        diag = field.delcd_ab_Fcd_ij(S, a=0, b=0)
+        S0 = S.with_changes(cs=full(-2.0 if kind != "cs3" else 0.0))     # no reaction
+        np.testing.assert_allclose((diag - field.delcd_ab_Fcd_ij(S0, a=0, b=0))[1:-1, 1:-1],
+                                   field.delcd_ab_cscd_reaction_ij(S, a=0, b=0)[1:-1, 1:-1]
+                                   - field.delcd_ab_cscd_reaction_ij(S0, a=0, b=0)[1:-1, 1:-1], rtol=1e-9,
+                                   atol=4e-16 * np.max(np.abs(diag)))     # a difference of two diagonals
+        for a, b in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+            for fn in (field.delT_ab_cscd_reaction_ij, field.delcl_ab_cscd_reaction_ij, field.delcd_ab_cscd_reaction_ij):
+                np.testing.assert_array_equal(fn(S, a=a, b=b), 0.0)
+        with pytest.raises(AssertionError):
+            field.delcl_ab_cscd_reaction_ij(S, a=1, b=1)
+
+
 REGHCS = json.load(open(os.path.join(GOLDEN, "golden_reghcs.json")))
 
 
@@ -537,6 +581,66 @@ def check_hcs_denominator_value_error():
     integ = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_HCsTriple(field, jacobi_sweeps=(50, 50, 50))
     with pytest.raises(ValueError):
         integ.step(p1.state_from_mms_when(mms_case=case, t=0.0, grid=grid), t0=0.0, dt=0.1)
+
+
+def _hcs_integrator_with_cs_source(grid, model, at_t0_value, later_value):
+    """HCsTriple integrator whose only forcing is fcs(t) = at_t0_value at t = 0 and later_value afterwards."""
+    nothing = lambda t, xx, yy: grid.make_full0()
+    fcs = lambda t, xx, yy: np.full(grid.full_shape, at_t0_value if np.isclose(t, 0.0) else later_value, dtype=float)
+    forcing = p1.ForcingTermsFromDict({"fcp": nothing, "fT": nothing, "fcl": nothing, "fcd": nothing, "fcs": fcs})
+    field = p1.SemiDiscreteField_HCsTriple(grid=grid, model=model, forcing_terms=forcing)
+    return p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_HCsTriple(semi_discrete_field=field)
+
+
+def _constant_state(grid, model, cs, cl=-1.0):
+    """cl = -1 switches the Cs/Cd interaction off at this state: Fcs then is the source alone."""
+    full = lambda v: np.full(grid.full_shape, v, dtype=float)
+    return p1.StateVars(full(0.1), full(0.2), full(cl), full(0.4), full(cs), model=model, hh=grid.hh, kk=grid.kk)
+
+
+def _zero_boundary(a):
+    return np.all(a[0, :] == 0) and np.all(a[-1, :] == 0) and np.all(a[:, 0] == 0) and np.all(a[:, -1] == 0)
+
+
+def check_hcs_cs_predictor_table():
+    """The known answers of reference tests/test_time_integrator_hcs_triple.py:182-256: the Heun predictor
+    cs0 + dt/2 (Fcs(t0) + Fcs*(t1)) is not clipped at zero, only the boundary is.  The reference prescribes
+    Fcs by overriding the field's method; here the same values come from the source term, with the
+    interaction switched off by cl = -1."""
+    model = model_of("nb_a", kind=1)
+    grid = p1.make_uniform_grid(4, 4)
+    for cs0, F0, F1, dt in ((1.0, 0.1, 0.2, 0.1), (0.01, -0.2, -0.2, 0.1), (-0.1, -0.1, -0.1, 0.1), (0.0, 0.0, 0.0, 0.1)):
+        integ = _hcs_integrator_with_cs_source(grid, model, F0, F1)
+        cs1 = integ.initial_cs_pred(_constant_state(grid, model, cs0), 0.0, dt=dt)
+        np.testing.assert_allclose(cs1[1:-1, 1:-1], cs0 + 0.5 * dt * (F0 + F1), rtol=1e-9, atol=1e-12)
+        assert _zero_boundary(cs1)
+
+
+def check_hcs_cs_corrector_table():
+    """The known answers of reference tests/test_time_integrator_hcs_triple.py:258-401: with
+    Y0 = 2 cs0 + dt (Fcs(t0) + fcs(t1)) and R1 = Kd (Sd - cd1)(1 + cl1) the corrector returns
+    Y0 / (2 - dt R1) where Y0 > 0 and Y0 / 2 elsewhere; and :403-498: ValueError when 2 - dt R1 <= 0."""
+    base = model_of("nb_a", kind=1)
+    grid = p1.make_uniform_grid(4, 4)
+    full = lambda v: np.full(grid.full_shape, v, dtype=float)
+    table = ((0.1, 0.5, 0.5, 0.5, 0.1), (0.01, 0.02, 0.02, 0.1, 0.01), (-0.1, -0.5, -0.5, 0.5, 0.1),
+             (-0.01, -0.02, -0.02, 10.0, 0.1), (0.0, 0.0, 0.0, 0.5, 0.1), (0.001, -0.02, 0.0, 1.0, 0.1),
+             (0.0, 1e-12, -1e-12, 1.0, 0.1))
+    for cs0, F0, f1, R1, dt in table:
+        model = base.with_changes(Kd=R1)
+        integ = _hcs_integrator_with_cs_source(grid, model, F0, f1)
+        cs1 = integ.corrector_cs_step(grid.make_full0(), full(0.0), full(model.Sd - 1.0),
+                                      at_t0=_constant_state(grid, model, cs0), t0=0.0, dt=dt)
+        Y0 = 2 * cs0 + dt * (F0 + f1)
+        expected = Y0 / (2.0 - dt * R1) if Y0 > 0 else Y0 / 2.0
+        np.testing.assert_allclose(cs1[1:-1, 1:-1], expected, rtol=1e-9, atol=1e-12, err_msg=str((cs0, F0, f1, R1, dt)))
+        assert _zero_boundary(cs1)
+    for dt, R1 in ((0.1, 20.0), (0.1, 21.0), (0.01, 200.0), (0.01, 200.1)):
+        model = base.with_changes(Kd=R1)
+        integ = _hcs_integrator_with_cs_source(grid, model, 0.1, 0.1)
+        with pytest.raises(ValueError, match="Denominator 2 - Δt Kd .* below positiveness treshold"):
+            integ.corrector_cs_step(grid.make_full0(), full(0.0), full(model.Sd - 1.0),
+                                    at_t0=_constant_state(grid, model, 0.1), t0=0.0, dt=dt)
 
 
 def check_integrator_pieces(kind):

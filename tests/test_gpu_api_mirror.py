@@ -165,3 +165,16 @@ def test_reghcs_scenarios_against_reference_numbers(eta):
 
 def test_cases_and_forcing_terms_evaluate_on_foreign_meshes():
     ac.check_foreign_mesh_evaluation()
+
+
+@pytest.mark.parametrize("kind", ["reg", "cs3", "hcs"])
+def test_interaction_law_accessors(kind):
+    ac.check_interaction_law_accessors(kind)
+
+
+def test_hcs_cs_predictor_known_answers():
+    ac.check_hcs_cs_predictor_table()
+
+
+def test_hcs_cs_corrector_known_answers_and_errors():
+    ac.check_hcs_cs_corrector_table()
