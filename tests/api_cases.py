@@ -261,6 +261,39 @@ def check_interaction_law_accessors(kind):
             field.delcl_ab_cscd_reaction_ij(S, a=1, b=1)
 
 
+def check_notebook_helpers(tmp_path):
+    """reference src/notebook_studies_helpers.py: the rate report that returns instead of raising, the two
+    figures (drawn off-screen), the template-cell replacement."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    import tedd.notebook_studies_helpers as nsh
+    errors = [1.0, 0.26, 0.0675, 0.0171]
+    rates, ok = nsh.report_on_rates(errors, expected_rate=2.0, tolerance=0.1, title="Spatial")
+    assert ok and len(rates) == 2 and rates[-1] == pytest.approx(1.93, abs=0.03)
+    assert nsh.report_on_rates([1.0, 0.6, 0.35, 0.2], expected_rate=2.0) == ([], False)
+    assert nsh.report_on_rates([1.0, 0.5, 0.25, 0.125], expected_rate=1.0, cmp_type="equal")[1]
+    nsh.plot_errors_and_rates(errors, rates, [8, 16, 32, 64], "N", "study", expected_rate=2.0)
+    nsh.plot_errors_and_rates(errors[:2], [], [8, 16], "N", "too short", log_scale=False)
+    model = model_of("nb_a")
+    nsh.visualize_mms_solution(p1mc.MMSCaseExpSin(grid=p1.make_uniform_grid(6, 6), model=model), time_point=0.1)
+    assert len(plt.get_fignums()) == 3
+    assert len(plt.figure(plt.get_fignums()[-1]).axes) == 11      # 6 panels + 5 colour bars
+    plt.close("all")
+    template = {"cells": [{"cell_type": "markdown", "metadata": {}, "source": ["# title"]},
+                          {"cell_type": "code", "metadata": {}, "outputs": [], "execution_count": None,
+                           "source": ["mms_case_cls = None\n"]}],
+                "metadata": {"kernelspec": {"name": "python3"}}, "nbformat": 4, "nbformat_minor": 5}
+    src, dst = tmp_path / "template.ipynb", tmp_path / "made.ipynb"
+    src.write_text(json.dumps(template), encoding="utf-8")
+    nsh.modify_notebook_cell(str(src), str(dst), 1, "import prob1_mms_cases as p1mc\nmms_case_cls = p1mc.MMSCasePol\n")
+    made = json.loads(dst.read_text(encoding="utf-8"))
+    assert "".join(made["cells"][1]["source"]).endswith("p1mc.MMSCasePol\n")
+    assert made["cells"][0] == template["cells"][0] and made["metadata"] == template["metadata"]
+    with pytest.raises(AssertionError):
+        nsh.modify_notebook_cell(str(src), str(dst), 2, "x")
+
+
 REGHCS = json.load(open(os.path.join(GOLDEN, "golden_reghcs.json")))
 
 

@@ -161,3 +161,7 @@ def test_hcs_cs_predictor_known_answers():
 
 def test_hcs_cs_corrector_known_answers_and_errors():
     ac.check_hcs_cs_corrector_table()
+
+
+def test_notebook_helpers(tmp_path):
+    ac.check_notebook_helpers(tmp_path)
