@@ -124,7 +124,7 @@ public:
     Ctx(const tedd_config& c, const double* x, const double* y) : cfg(c) {
         N = c.N;
         M = c.M;
-        if (N < 2 || M < 2) throw InvalidError("mesh needs N >= 2 and M >= 2");
+        if (N < 1 || M < 1) throw InvalidError("mesh needs N >= 1 and M >= 1");
         if (c.row_lo < 0 || c.row_hi > N + 1 || c.row_lo >= c.row_hi) throw InvalidError("bad row range");
         if (c.ghost < 0) throw InvalidError("ghost < 0");
         if (c.model_kind != 1 && c.model_kind != 2) throw InvalidError("model_kind must be 1 or 2");

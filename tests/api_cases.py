@@ -24,6 +24,8 @@ CASES = {
     "pol": (p1mc.MMSCasePol, "nb_b", 0.01),
     "peaks_fast1e1": (p1mc.MMSCaseSlowlyChangingPeaks_Fast1e1, "nb_b", 1.0),
     "nfs_h2_h3": (p1mc.MMSCaseNonFullySmoothPol_cpcsH2_TclcdH3, "nb_a", 1.0),
+    "nfs_h1_h2": (p1mc.MMSCaseNonFullySmoothPol_cpcsH1_TclcdH2, "nb_a", 1.0),
+    "nfs_h2_h2": (p1mc.MMSCaseNonFullySmoothPol_cpcsH2_TclcdH2, "nb_a", 1.0),
 }
 # cases stated symbolically (forcing evaluated on the host and streamed); sympy is optional
 if p1mc.sympy is not None:
@@ -97,6 +99,54 @@ def check_published_errors(case_name, levels, rel):
         for mine, ref in zip(rates[-len(printed):], printed):
             assert mine == pytest.approx(ref, abs=2e-3), (case_name, rates, printed)
     return out
+
+
+def check_published_temporal_study(case_name, rel, max_n=None):
+    """The temporal studies printed in the reference's executed notebooks: fixed mesh (N = 256, or 32 for
+    ExpSin) and dt halved from 1e-2 to Tf = 0.01; the Peaks notebook instead refines the mesh with the step
+    (N = ceil(1 / (2 dt)), Tf = 10: from a 1 x 1 mesh without interior nodes, error 0, through O(1) errors at
+    dt = 1/4 to the asymptotic range).  Errors to the printed digits, and the printed 3-point rates."""
+    cls, mset, _Tf = CASES[case_name]
+    study = PUBLISHED[case_name]["temporal"]
+    model = model_of(mset)
+    errors = []
+    for lev in study["levels"]:
+        N = lev.get("N", study["N"])
+        if max_n is not None and N > max_n:
+            break
+        summ = reg_trial(cls, model, N).run_for_errors(Tf=study["Tf"], dt=lev["dt"])
+        assert summ.overall_combined_error == pytest.approx(lev["overall"], rel=rel, abs=1e-300), (case_name, lev)
+        errors.append(summ.overall_combined_error)
+    if len(errors) == len(study["levels"]) and study["rates_3pt"]:
+        from tedd.cvg_studies_base import calculate_observed_rates
+        rates = [r for r, _status in calculate_observed_rates(errors, 2.0) if np.isfinite(r)]
+        assert rates == pytest.approx(study["rates_3pt"], abs=2e-3), (case_name, rates)
+    return errors
+
+
+def check_tiny_meshes():
+    """Meshes down to a single cell (1 x 1: no interior node; the Peaks notebook's temporal study starts there):
+    a step returns the boundary values of the exact solution and, where there are interior nodes, stays close
+    to it."""
+    model = model_of("nb_b")
+    for N, M in ((1, 1), (1, 3), (3, 1), (2, 2), (1, 2)):
+        grid = p1.make_uniform_grid(N, M)
+        for name in ("peaks_fast1e1", "expsin"):
+            trial = reg_trial(CASES[name][0], model, N, M=M)
+            case = trial.mms_case
+            S = trial.integrator.step(p1.state_from_mms_when(mms_case=case, t=0.0, grid=grid), t0=0.0, dt=0.01)
+            E = p1.state_from_mms_when(mms_case=case, t=0.01, grid=grid)
+            for v in ("cp", "T", "cl", "cd", "cs"):
+                got, want = getattr(S, v), getattr(E, v)
+                assert got.shape == (N + 1, M + 1) and np.all(np.isfinite(got))
+                bd = grid.null_bd_mask == 0
+                if v in ("T", "cl", "cd"):
+                    np.testing.assert_allclose(got[bd], want[bd], rtol=0, atol=1e-15, err_msg=f"{N}x{M} {name} {v}")
+                np.testing.assert_allclose(got, want, rtol=0, atol=1e-2, err_msg=f"{N}x{M} {name} {v}")
+            summ = trial.run_for_errors(Tf=0.02, dt=0.01)
+            assert np.isfinite(summ.overall_combined_error)
+            if N == 1 or M == 1:
+                assert summ.per_variable_sup_errors["T"] < 1e-15
 
 
 SCALARS = json.load(open(os.path.join(GOLDEN, "golden_scalars.json")))

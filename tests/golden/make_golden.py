@@ -701,6 +701,8 @@ def gen_published():
         "pol": "MMSCasePol_reghcstriple_convergence_study.ipynb",
         "peaks_fast1e1": "MMSCaseSlowlyChangingPeaks_Fast1e1_reghcstriple_convergence_study.ipynb",
         "nfs_h2_h3": "MMSCaseNonFullySmoothPol_cpcsH2_TclcdH3_reghcstriple_convergence_study.ipynb",
+        "nfs_h1_h2": "MMSCaseNonFullySmoothPol_cpcsH1_TclcdH2_reghcstriple_convergence_study.ipynb",
+        "nfs_h2_h2": "MMSCaseNonFullySmoothPol_cpcsH2_TclcdH2_reghcstriple_convergence_study.ipynb",
     }
     for cname, fn in nbs.items():
         nb = json.load(open(os.path.join(REF_ROOT, fn)))
@@ -723,7 +725,27 @@ def gen_published():
                 levels.append({"N": n, "overall": overall, "per_variable": per, "wall_s": wall})
             rates = [float(m.group(1)) for m in
                      re.finditer(r"Levels \d+,\d+,\d+: .* = ([0-9.]+)", text)]
-            res[cname] = {"notebook": fn, "levels": levels, "rates_3pt": rates}
+            tf = float(re.search(r"^Tf = ([0-9.e+-]+)", src, re.M).group(1))
+            res[cname] = {"notebook": fn, "Tf": tf, "levels": levels, "rates_3pt": rates}
+        # the temporal study: fixed mesh, dt halved, overall error per level
+        for cell in nb["cells"]:
+            src = "".join(cell["source"]) if cell["cell_type"] == "code" else ""
+            if "Temporal Convergence Study" not in src:
+                continue
+            text = "".join("".join(o.get("text", "")) for o in cell.get("outputs", [])
+                           if o.get("output_type") == "stream")
+            ns = {}
+            for name in ("FIXED_GRID_SIZE", "BASE_DT", "Tf"):
+                expr = re.search(rf"^{name} = ([^#\n]+)", src, re.M).group(1)
+                assert re.fullmatch(r"[0-9.e+\-* ]+", expr.strip()), expr     # plain arithmetic only
+                ns[name] = eval(expr, {"__builtins__": {}})
+            # (the Peaks notebook refines the mesh with the step, N = ceil(1 / (2 dt)), and prints N per level)
+            rows = [dict({"dt": float(m.group(1)), "overall": float(m.group(3))}, **({"N": int(m.group(2))} if m.group(2) else {}))
+                    for m in re.finditer(r"Running simulation with dt = ([0-9.e+-]+)\n(?:(\d+)\n)?\s+Completed in [0-9.e+-]+ seconds"
+                                         r"\n\s+Overall error: ([0-9.e+-]+)", text)]
+            trates = [float(m.group(1)) for m in re.finditer(r"Levels \d+,\d+,\d+: .* = ([0-9.]+)", text)]
+            res[cname]["temporal"] = {"N": int(ns["FIXED_GRID_SIZE"]), "Tf": float(ns["Tf"]), "base_dt": float(ns["BASE_DT"]),
+                                      "levels": rows, "rates_3pt": trates}
     with open(os.path.join(HERE, "published_notebook_errors.json"), "w") as f:
         json.dump(res, f, indent=1)
     print("published_notebook_errors.json written")

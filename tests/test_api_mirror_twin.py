@@ -165,3 +165,17 @@ def test_hcs_cs_corrector_known_answers_and_errors():
 
 def test_notebook_helpers(tmp_path):
     ac.check_notebook_helpers(tmp_path)
+
+
+@pytest.mark.parametrize("case,max_n", [("expsin", 32), ("peaks_fast1e1", 16)])
+def test_published_temporal_studies_coarse_levels(case, max_n):
+    ac.check_published_temporal_study(case, 2e-9, max_n=max_n)
+
+
+@pytest.mark.parametrize("case", ["nfs_h1_h2", "nfs_h2_h2"])
+def test_published_errors_of_the_rougher_variants(case):
+    ac.check_published_errors(case, (2, 4, 8, 16), 2e-9)
+
+
+def test_meshes_down_to_one_cell():
+    ac.check_tiny_meshes()

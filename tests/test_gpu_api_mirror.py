@@ -26,7 +26,9 @@ def test_classes_instantiation():
     ("expsin", (2, 4, 8, 16, 32, 64, 128, 256), 2e-9),      # N=256: the published finest-mesh run (41 steps)
     ("pol", (2, 4, 8, 16, 32, 64, 128, 256), 5e-6),
     ("peaks_fast1e1", (2, 4, 8, 16, 32, 64, 128, 256), 2e-9),   # N=256: 4096 steps to Tf=1
-    ("nfs_h2_h3", (2, 4, 8, 16, 32, 64, 128, 256), 2e-9)])      # the full spatial sweep of the notebook
+    ("nfs_h2_h3", (2, 4, 8, 16, 32, 64, 128, 256), 2e-9),      # the full spatial sweep of the notebook
+    ("nfs_h1_h2", (2, 4, 8, 16, 32, 64, 128, 256), 2e-9),      # the two notebooks of the rougher variants
+    ("nfs_h2_h2", (2, 4, 8, 16, 32, 64, 128, 256), 2e-9)])
 def test_published_notebook_errors(case, levels, rel):
     ac.check_published_errors(case, levels, rel)
 
@@ -35,6 +37,13 @@ def test_published_notebook_errors(case, levels, rel):
 def test_error_norms_of_reference_runs(case, max_n):
     # relative 2e-9: Jacobi to 1e-13 instead of SuperLU, summed over up to 4096 steps
     ac.check_reference_run_errors(case, max_n, 2e-9)
+
+
+@pytest.mark.parametrize("case,rel", [("expsin", 2e-9), ("pol", 5e-6), ("peaks_fast1e1", 2e-9), ("nfs_h2_h3", 2e-9),
+                                      ("nfs_h1_h2", 2e-9), ("nfs_h2_h2", 2e-9)])
+def test_published_temporal_studies(case, rel):
+    # Peaks: mesh refined with the step from 1 x 1 (no interior node) to 128 x 128, Tf = 10, 2560 steps at the end
+    ac.check_published_temporal_study(case, rel)
 
 
 def test_temporal_study_of_reference_runs():
@@ -178,3 +187,7 @@ def test_hcs_cs_predictor_known_answers():
 
 def test_hcs_cs_corrector_known_answers_and_errors():
     ac.check_hcs_cs_corrector_table()
+
+
+def test_meshes_down_to_one_cell():
+    ac.check_tiny_meshes()
