@@ -221,3 +221,44 @@ class SlabStepper:
     def step_feuler(self, t0, dt):
         self.ctx.step_feuler(t0, dt)
         self.refresh_ghosts()
+
+
+# ------------------------------------------------------------------------------------------
+# Convergence sweeps: independent runs, sharded across ranks without any data-path collective
+# ------------------------------------------------------------------------------------------
+def assign_levels(costs, world: int):
+    """Longest-processing-time assignment of independent runs to ranks: returns, per rank, the indices of
+    the runs it executes.  `costs` are relative run times (for a study level on an N x N mesh with dt ~ h^1.5:
+    N^2 nodes x N^1.5 steps); ties and the order inside a rank are deterministic, so every rank computes the
+    same assignment without talking to the others."""
+    order = sorted(range(len(costs)), key=lambda k: (-float(costs[k]), k))
+    load = [0.0] * world
+    mine = [[] for _ in range(world)]
+    for k in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        mine[r].append(k)
+        load[r] += float(costs[k])
+    return [sorted(m) for m in mine]
+
+
+def run_levels_sharded(levels, run_one, costs=None, group=None):
+    """Runs `run_one(level)` for every level of a convergence sweep, each level on one rank (the levels of
+    a sweep are independent simulations: reference src/cvg_studies_base.py:364-470 runs them one after the
+    other), and returns the list of results in the order of `levels` on every rank.  The only communication
+    is the gather of the results (picklable Python objects) at the end."""
+    import torch.distributed as dist
+    levels = list(levels)
+    if not (dist.is_available() and dist.is_initialized()):
+        return [run_one(lv) for lv in levels]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    costs = [1.0] * len(levels) if costs is None else list(costs)
+    if len(costs) != len(levels):
+        raise ValueError("one cost per level")
+    plan = assign_levels(costs, world)
+    local = {k: run_one(levels[k]) for k in plan[rank]}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local, group=group)
+    merged = {}
+    for part in gathered:
+        merged.update(part)
+    return [merged[k] for k in range(len(levels))]

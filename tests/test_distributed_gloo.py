@@ -146,3 +146,47 @@ def test_too_few_ghost_rows_is_an_error(tmp_path):
     with pytest.raises(ValueError, match="ghost"):
         ctx.step_pc(0.0, 0.01, jacobi_sweeps=[4, 3, 2])
     ctx.close()
+
+
+# ---- convergence sweeps: independent levels sharded across ranks
+def test_level_assignment_is_balanced_and_complete():
+    from tedd.distributed import assign_levels
+    costs = [2.0 ** (3.5 * k) for k in range(8)] + [300.0, 600.0, 1200.0, 2400.0]
+    for world in (1, 2, 3, 8, 16):
+        plan = assign_levels(costs, world)
+        assert sorted(k for part in plan for k in part) == list(range(len(costs)))
+        loads = [sum(costs[k] for k in part) for part in plan]
+        assert max(loads) <= max(costs) + sum(costs) / world     # the LPT bound
+    assert assign_levels([1, 1, 1, 1], 2) == [[0, 2], [1, 3]]
+    assert assign_levels([], 3) == [[], [], []]
+
+
+def _sweep_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import contextlib
+    import io
+    from test_twin_cabi_parity import TWIN
+    sys.argv = ["sweep_sharded.py", "--case", "expsin", "--backend", "gloo", "--library", TWIN, "--max-n", "32"]
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sweep_sharded
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        sweep_sharded.main()
+    with open(os.path.join(out_dir, f"sweep{rank}.txt"), "w") as f:
+        f.write(buf.getvalue())
+
+
+def test_sharded_sweep_reproduces_the_notebook(tmp_path):
+    """tools/sweep_sharded.py on two gloo ranks over the host twin: ExpSin levels up to N = 32 of the spatial
+    sweep plus the N = 32 temporal study, against the notebook's printed errors."""
+    import json
+    from test_twin_cabi_parity import build_twin
+    build_twin()
+    port = 29500 + (os.getpid() % 2000) + 7
+    mp.spawn(_sweep_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    out = json.loads((tmp_path / "sweep0.txt").read_text().strip().splitlines()[-1])
+    assert (tmp_path / "sweep1.txt").read_text().strip() == ""
+    assert out["ranks"] == 2 and out["levels"] == 5 + 6
+    assert out["worst_relative_difference_to_notebook"] < 2e-9
+    assert out["spatial_rates_3pt"] == pytest.approx(out["notebook_rates_3pt"][:3], abs=2e-3)
