@@ -19,8 +19,10 @@ namespace tedd {
 #define TEDD_HIP(call)                                                                              \
     do {                                                                                            \
         hipError_t e_ = (call);                                                                     \
-        if (e_ != hipSuccess)                                                                       \
+        if (e_ != hipSuccess) {                                                                     \
+            (void)hipGetLastError(); /* reported here: must not surface again at a later launch check */ \
             throw std::runtime_error(std::string(#call) + " failed: " + hipGetErrorString(e_));    \
+        }                                                                                           \
     } while (0)
 
 constexpr int kTileX = 64, kTileY = 4, kMaxReduceBlocks = 2048;

@@ -157,3 +157,30 @@ def test_tile_shapes_and_depths_bit_identical(N, M, react):
             for a, b, c in zip(out, first, ref):
                 np.testing.assert_array_equal(a, b, err_msg=f"shape {shape} depth {hmax}")
                 assert np.max(np.abs(a - c)) <= 1e-14 * max(1.0, np.max(np.abs(c)))
+
+
+def test_out_of_memory_is_an_error_and_leaves_the_library_usable():
+    """A mesh whose fields cannot be allocated (100001^2 nodes: 80 GB per array) fails with RuntimeError at the
+    first call that needs the arrays; contexts made before and after keep working."""
+    from tedd import _ffi
+
+    def small():
+        x = np.linspace(0, 1, 33)
+        return _ffi.Context(x, x, NB_A, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+                            mms_case=_ffi.MMS_EXPSIN)
+    before = small()
+    before.set_state_exact(0.0)
+    x = np.linspace(0, 1, 100001)
+    big = _ffi.Context(x, x, NB_A, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+                       mms_case=_ffi.MMS_EXPSIN)
+    with pytest.raises(RuntimeError, match="memory|hipMalloc"):
+        big.set_state_exact(0.0)
+        big.step_pc(0.0, 1e-8)
+    big.close()
+    after = small()
+    after.set_state_exact(0.0)
+    for ctx in (before, after):
+        ctx.step_pc(0.0, 1e-3)
+        ctx.sync()
+        assert np.sqrt(ctx.error_norms(1e-3)[:5].sum()) < 1e-4
+        ctx.close()
