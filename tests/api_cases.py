@@ -86,9 +86,11 @@ def check_published_errors(case_name, levels, rel):
             continue
         trial = reg_trial(cls, model, N)
         summ = trial.run_for_errors(Tf=Tf, dt=(1.0 / N) ** 1.5)
-        assert summ.overall_combined_error == pytest.approx(lev["overall"], rel=rel), (case_name, N)
+        # (pytest.approx keeps its default absolute tolerance of 1e-12 unless abs is given: give it always.
+        #  An error norm is a norm of differences of O(1) fields, so it carries their rounding, ~1e-17 absolute)
+        assert summ.overall_combined_error == pytest.approx(lev["overall"], rel=rel, abs=1e-17), (case_name, N)
         for v, val in lev["per_variable"].items():
-            assert summ.per_variable_sup_errors[v] == pytest.approx(val, rel=1e-4, abs=1e-16), (case_name, N, v)
+            assert summ.per_variable_sup_errors[v] == pytest.approx(val, rel=max(rel, 5e-9), abs=2e-17), (case_name, N, v)
         out.append(summ.overall_combined_error)
     # observed 3-point rates of this sweep against the ones the notebook prints (3 decimals)
     all_levels = [lev["N"] for lev in PUBLISHED[case_name]["levels"]]
@@ -115,7 +117,7 @@ def check_published_temporal_study(case_name, rel, max_n=None):
         if max_n is not None and N > max_n:
             break
         summ = reg_trial(cls, model, N).run_for_errors(Tf=study["Tf"], dt=lev["dt"])
-        assert summ.overall_combined_error == pytest.approx(lev["overall"], rel=rel, abs=1e-300), (case_name, lev)
+        assert summ.overall_combined_error == pytest.approx(lev["overall"], rel=rel, abs=1e-17), (case_name, lev)
         errors.append(summ.overall_combined_error)
     if len(errors) == len(study["levels"]) and study["rates_3pt"]:
         from tedd.cvg_studies_base import calculate_observed_rates
@@ -165,10 +167,10 @@ def check_reference_run_errors(case_name, max_n, rel):
             continue
         summ = reg_trial(cls, model, N).run_for_errors(Tf=Tf, dt=(1.0 / N) ** 1.5)
         assert summ.dt_used == pytest.approx(lev["dt_used"], rel=1e-15), (case_name, N)
-        assert summ.overall_combined_error == pytest.approx(lev["overall"], rel=rel), (case_name, N)
+        assert summ.overall_combined_error == pytest.approx(lev["overall"], rel=rel, abs=1e-17), (case_name, N)
         for v, val in lev["per_variable"].items():
             # errors far below the O(1) fields carry the rounding of the fields themselves (~1e-16 absolute)
-            assert summ.per_variable_sup_errors[v] == pytest.approx(val, rel=10 * rel, abs=1e-15), (case_name, N, v)
+            assert summ.per_variable_sup_errors[v] == pytest.approx(val, rel=10 * rel, abs=1e-16), (case_name, N, v)
 
 
 def check_reference_temporal_study(rel):
@@ -177,7 +179,7 @@ def check_reference_temporal_study(rel):
     model = model_of(mset)
     for row in SCALARS["expsin_temporal_N32"]:
         summ = reg_trial(cls, model, 32).run_for_errors(Tf=0.01, dt=row["dt"])
-        assert summ.overall_combined_error == pytest.approx(row["overall"], rel=rel), row["dt"]
+        assert summ.overall_combined_error == pytest.approx(row["overall"], rel=rel, abs=1e-17), row["dt"]
 
 
 ISOLATED = json.load(open(os.path.join(GOLDEN, "golden_isolated.json")))
@@ -196,7 +198,7 @@ def check_isolated_operator_truncation(which):
     pytest.importorskip("sympy")
     import isolated_cases
     errors = isolated_cases.operator_truncation_errors(p1, which)
-    assert errors == pytest.approx(ISOLATED["operators"][which], rel=1e-7), which
+    assert errors == pytest.approx(ISOLATED["operators"][which], rel=1e-7, abs=0), which
     _final_rate_at_least(errors)
 
 
@@ -452,7 +454,7 @@ def check_run_convergence_studies(label, rel, fused=True):
     for study in ("spatial", "temporal"):
         mine, theirs = rep[label][study], ref["report"][study]
         assert set(mine) == {"errors", "rates", "statuses"}
-        assert mine["errors"] == pytest.approx(theirs["errors"], rel=rel), (label, study)
+        assert mine["errors"] == pytest.approx(theirs["errors"], rel=rel, abs=0), (label, study)
         assert mine["statuses"] == theirs["statuses"], (label, study)
         for a, b in zip(mine["rates"], theirs["rates"]):
             if b is None:
@@ -471,7 +473,7 @@ def check_fused_equals_stepwise(case_name, N, nsteps_Tf):
     a = reg_trial(cls, model, N, fused=True).run_for_errors(Tf=nsteps_Tf * dt, dt=dt)
     b = reg_trial(cls, model, N, fused=False).run_for_errors(Tf=nsteps_Tf * dt, dt=dt)
     assert a.dt_used == b.dt_used
-    assert a.overall_combined_error == pytest.approx(b.overall_combined_error, rel=1e-9)
+    assert a.overall_combined_error == pytest.approx(b.overall_combined_error, rel=1e-9, abs=0)
     for v in a.per_variable_sup_errors:
         assert a.per_variable_sup_errors[v] == pytest.approx(b.per_variable_sup_errors[v], rel=1e-7, abs=1e-18)
 
