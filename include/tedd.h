@@ -56,7 +56,8 @@ enum tedd_reaction {
 };
 
 typedef struct tedd_config {
-    int32_t N, M;             /* mesh has (N+1) x (M+1) nodes */
+    int32_t N, M;             /* mesh has (N+1) x (M+1) nodes; N, M >= 1 (a 1 x 1 mesh has no interior node:
+                                 a step then only sets the boundary values) */
     int32_t row_lo, row_hi;   /* owned global rows [row_lo, row_hi); 0 and N+1 on a single device */
     int32_t ghost;            /* ghost rows kept on each non-physical side (0 on a single device) */
     int32_t model_kind;       /* 1 = DefaultModel01, 2 = DefaultModel02 (src/prob1base.py:71-217) */
