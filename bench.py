@@ -321,7 +321,7 @@ def main():
     forcing_mode = ("closed form inside the step kernels" if not args.cache_forcing else
                     "arrays per time level, made by the predictor launch" if args.fuse_forcing else "arrays per time level")
     cfg_key = {"mesh_N": N, "solver": args.solver, "sweeps_per_launch": args.hmax, "forcing": forcing_mode}
-    if roofline is not None:
+    if roofline is not None and world == 1:   # the committed counter passes are whole-mesh launches on one GPU
         tr = pmc_traffic(fam, cfg_key)
         if tr is not None:
             roofline["traffic"] = tr["bytes_per_launch"]
