@@ -539,13 +539,37 @@ class MMSCaseDevice(MMSCaseBase):
         return s
 
     def _eval(self, what, t, xx, yy):
-        grid = self._meshes.grid_for(self._grid, xx, yy)
+        try:
+            grid = self._meshes.grid_for(self._grid, xx, yy)
+        except NotImplementedError:
+            return self._eval_points(what, t, xx, yy)
         key = (what, float(t), tuple(self._model.consts_vector()), id(grid))
         if key not in self._memo:
             self._memo.clear()
             self._memo[key] = self._device(grid).ctx.eval_mms(t, what)
             self._memo["grid"] = grid      # keeps id(grid) unambiguous while the entry lives
         return self._memo[key]
+
+    _MAX_POINT_MESH = 1 << 22
+
+    def _eval_points(self, what, t, xx, yy):
+        """Values at points that are not the nodes of a tensor-product mesh (a scalar pair, a line of points,
+        ...), as the reference's cases allow: the device evaluates on the mesh of the distinct coordinates and
+        the points are picked out of it."""
+        px, py = np.broadcast_arrays(np.asarray(xx, dtype=float), np.asarray(yy, dtype=float))
+        xs, ix = np.unique(px.ravel(), return_inverse=True)
+        ys, iy = np.unique(py.ravel(), return_inverse=True)
+
+        def padded(axis):       # a device mesh needs three increasing coordinates per axis
+            extra = [axis[-1] + k for k in range(1, 4 - len(axis))] if len(axis) < 3 else []
+            return np.concatenate([axis, np.asarray(extra, dtype=float)])
+        xs, ys = padded(xs), padded(ys)
+        if not (np.all(np.isfinite(xs)) and np.all(np.isfinite(ys))) or len(xs) * len(ys) > self._MAX_POINT_MESH:
+            raise NotImplementedError("too many distinct coordinates for pointwise evaluation on the device; "
+                                      "hand over the nodes of a tensor-product mesh")
+        mx, my = np.meshgrid(xs, ys, indexing="ij")
+        values = self._eval(what, t, mx, my)
+        return [np.asarray(v)[ix.ravel(), iy.ravel()].reshape(px.shape) for v in values]
 
     def exact_fields(self, t):
         return [a.copy() for a in self._eval(0, t, None, None)]

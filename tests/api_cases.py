@@ -254,9 +254,23 @@ def check_foreign_mesh_evaluation():
         steps.append(S)
     for v in ("cp", "T", "cl", "cd", "cs"):
         np.testing.assert_array_equal(getattr(steps[0], v), getattr(steps[1], v))
-    # scattered points are not a mesh
-    with pytest.raises(NotImplementedError):
-        case.T(0.3, np.random.default_rng(0).random((4, 4)), np.random.default_rng(1).random((4, 4)))
+    # scattered points, a line of points, a single point: evaluated through the mesh of their coordinates
+    rng = np.random.default_rng(0)
+    big = p1mc.MMSCaseExpSin(grid=p1.make_uniform_grid(N=9, M=7), model=model)
+    gx, gy = big.grid.xx, big.grid.yy
+    pick = (np.array([3, 0, 9, 5, 5]), np.array([2, 7, 0, 4, 2]))
+    for name in ("cp", "T", "dt_cs", "dx_T", "lap_cd"):
+        on_mesh = getattr(big, name)(0.3, gx, gy)
+        np.testing.assert_array_equal(getattr(case, name)(0.3, gx[pick], gy[pick]), on_mesh[pick])
+        single = getattr(case, name)(0.3, gx[3, 2], gy[3, 2])
+        assert np.shape(single) == () and float(single) == on_mesh[3, 2]
+        line = getattr(case, name)(0.3, gx[:, 4], gy[:, 4])
+        np.testing.assert_array_equal(line, on_mesh[:, 4])
+    px, py = rng.random((4, 5)), rng.random((4, 5))
+    vals = case.T(0.3, px, py)
+    assert vals.shape == (4, 5) and np.all(np.isfinite(vals))
+    one = p1mc.MMSCaseExpSin(grid=p1.Grid(np.sort(np.append(px[0], [0, 1])), np.sort(np.append(py[0], [0, 1]))), model=model)
+    np.testing.assert_allclose(vals[0], [float(one.T(0.3, a, b)) for a, b in zip(px[0], py[0])], rtol=1e-15)
     # a host-evaluated case: cell averages follow the mesh handed in
     if p1mc.sympy is not None:
         t, x, y = p1.t_sym, p1.x_sym, p1.y_sym
