@@ -193,6 +193,17 @@ int tedd_eval_jacobian(tedd_ctx* ctx, int32_t op, double* c, double* e, double* 
  * (src/mms_trial_utils.py:81-110).  For TEDD_MMS_STREAM pass the exact fields in exact[5]. */
 int tedd_error_norms(tedd_ctx* ctx, double t, const double* const exact[5], double out[8]);
 
+/* tedd_error_norms for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same kernels and the same sums,
+ * bit for bit, as tedd_error_norms for a closed-form MMS case, but the call allocates nothing on the host
+ * runtime or the device: the per-workgroup partial sums go to a fixed 128 KiB array in the library's device
+ * image instead of the context's buffer, no timing events are taken, and the 8 results are written to
+ * out_device, device memory of the caller (8 doubles), by work enqueued on the context's stream -- the
+ * call does not synchronise.  Limits: closed-form cases only (TEDD_MMS_POL .. TEDD_MMS_NFS), slabs of at
+ * most 2^26 nodes; anything else is TEDD_ERR_INVALID.  Every call on a GPU shares that GPU's array: calls
+ * that overlap in time on one GPU (two contexts on different streams) race. */
+int tedd_error_norms_noalloc(tedd_ctx* ctx, double t, double* out_device);
+
 /* Record of the last step: sweeps[3] Jacobi sweeps used for T, cl, cd; last_update[3] and
  * increment[3]: max-norms of the last sweep's update and of the solution increment;
  * cs_iterations: Newton iterations the cs corrector kept (global early exit, src/prob1base.py:3661). */

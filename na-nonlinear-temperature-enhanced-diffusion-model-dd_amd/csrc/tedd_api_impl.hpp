@@ -228,6 +228,9 @@ int tedd_error_norms(tedd_ctx* ctx, double t, const double* const exact[5], doub
         C.error_norms(t, exact, out);
     });
 }
+int tedd_error_norms_noalloc(tedd_ctx* ctx, double t, double* out_device) {
+    return guarded(ctx, [&](auto& C) { C.error_norms_noalloc(t, out_device); });
+}
 int tedd_get_stats(tedd_ctx* ctx, tedd_step_stats* out) {
     return guarded(ctx, [&](auto& C) {
         if (!out) throw tedd::InvalidError("out is null");

@@ -718,6 +718,7 @@ public:
         Ctx* c;
         double t;
         double* dev_out;
+        bool noalloc = false;
         template <int CASE, int REACT>
         void run() {
             Ctx& C = *c;
@@ -737,9 +738,26 @@ public:
             Range r = C.need({{C.cur[1], true}, {C.cur[2], true}, {C.cur[3], true}});
             if ((C.gl > 0 || C.gr > 0) && (r.lo > o.lo || r.hi < o.hi))
                 throw InvalidError("ghost rows are stale: exchange them before taking norms");
-            C.be.nodes_sum(FAM_NORMS, f, o.lo, o.hi, C.ncols, dev_out);
+            if (noalloc)
+                C.be.nodes_sum_noalloc(f, o.lo, o.hi, C.ncols, dev_out);
+            else
+                C.be.nodes_sum(FAM_NORMS, f, o.lo, o.hi, C.ncols, dev_out);
         }
     };
+    // Largest slab tedd_error_norms_noalloc accepts (nodes, ghost rows included): 2^26, a quarter of the
+    // 16384^2 mesh.  The limit is a promise about the fixed scratch array, not a property of the kernel.
+    static constexpr long long kNoallocMaxNodes = 1LL << 26;
+    void error_norms_noalloc(double t, double* dev_out) {
+        require_state();
+        if (!dev_out) throw InvalidError("out is null");
+        if (mms_case == CASE_STREAM || mms_case == CASE_PROG)
+            throw InvalidError("tedd_error_norms_noalloc needs a closed-form MMS case (the others keep the exact "
+                               "fields in buffers that would have to be allocated)");
+        if ((long long)nrows * ncols > kNoallocMaxNodes)
+            throw InvalidError("tedd_error_norms_noalloc: slab larger than 2^26 nodes");
+        NormOp op{this, t, dev_out, true};
+        dispatch(op);
+    }
     void error_norms_async(double t, double* dev_out) {
         require_state();
         NormOp op{this, t, dev_out};

@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -26,6 +27,16 @@ namespace tedd {
     } while (0)
 
 constexpr int kTileX = 64, kTileY = 4, kMaxReduceBlocks = 2048;
+
+// Scratch of the entry point that allocates nothing (tedd_error_norms_noalloc): the per-workgroup partial
+// sums of the error norms, kMaxReduceBlocks x 8 doubles = 128 KiB.  Every GPU the library runs on holds
+// its own copy of this array at its own address until the process ends; host code never uses the array's
+// name as an address: HipBackend::init asks the runtime for the copy's address on the current device
+// (hipGetSymbolAddress) once per device and passes that pointer to the kernels.
+constexpr int kScratchSums = 8;
+constexpr size_t kScratchDoubles = (size_t)kMaxReduceBlocks * kScratchSums;
+static __device__ __align__(256) double scratch[kScratchDoubles];
+constexpr int kMaxDevices = 64;
 
 template <class F>
 __global__ void __launch_bounds__(256) k_nodes(const F f, int r0, int r1, int ncols) {
@@ -304,6 +315,7 @@ struct HipBackend {
     int device = -1;
     int num_cus = 256;
     double* d_partials = nullptr;
+    double* d_scratch = nullptr;              // this device's copy of the static scratch array
     unsigned long long* d_csstats = nullptr;  // [4096] max, [4096] min
     int cs_record_clean = 0;                  // leading entries of both known to hold their initial values
     bool profiling = false;
@@ -324,6 +336,7 @@ struct HipBackend {
         TEDD_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, device));
         TEDD_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         own_stream = true;
+        d_scratch = scratch_on_device(device);
         d_partials = (double*)alloc((size_t)kMaxReduceBlocks * 8 * sizeof(double));
         d_csstats = (unsigned long long*)alloc(2 * 4096 * sizeof(unsigned long long));
     }
@@ -354,6 +367,21 @@ struct HipBackend {
         own_stream = false;
     }
     void use_device() { TEDD_HIP(hipSetDevice(device)); }
+    // Address of the static scratch array on device `dev` (which must be the current device); looked up
+    // once per device and kept for the life of the process.
+    static double* scratch_on_device(int dev) {
+        static std::mutex mu;
+        static double* ptr[kMaxDevices] = {nullptr};
+        if (dev < 0 || dev >= kMaxDevices) throw std::runtime_error("device ordinal out of range");
+        std::lock_guard<std::mutex> lock(mu);
+        if (!ptr[dev]) {
+            double* p = nullptr;
+            TEDD_HIP(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+            if (!p) throw std::runtime_error("hipGetSymbolAddress returned a null scratch address");
+            ptr[dev] = p;
+        }
+        return ptr[dev];
+    }
     void* alloc(size_t bytes) {
         void* p = nullptr;
         TEDD_HIP(hipMalloc(&p, bytes));
@@ -567,6 +595,27 @@ struct HipBackend {
         tiling(r0, r1, ncols, tx, nt, nb);
         hipLaunchKernelGGL(k_nodes_sum<F>, dim3(nb), dim3(kTileX, kTileY), 0, stream, f, r0, r1, ncols, tx, nt, d_partials);
         hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64, F::NR), 0, stream, d_partials, nb, (int)F::NR, dev_out);
+        TEDD_HIP(hipGetLastError());
+    }
+    // nodes_sum without any allocation: the partial sums go to this device's static scratch array, no
+    // timing events are taken, and dev_out is the caller's device memory (F::NR doubles).  The partials
+    // of min(tiles, kMaxReduceBlocks) workgroups are overwritten before the final pass reads exactly that
+    // many, so nothing of an earlier (larger) call is ever read.  Calls that overlap on one GPU (two
+    // streams, two contexts) race on the array.
+    template <class F>
+    void nodes_sum_noalloc(const F& f, int r0, int r1, int ncols, double* dev_out) {
+        static_assert(F::NR <= kScratchSums, "scratch holds at most kScratchSums sums per workgroup");
+        check_range(r0, r1, ncols);
+        if (!d_scratch) throw std::runtime_error("static scratch address not initialised");
+        if (r1 == r0) {
+            TEDD_HIP(hipMemsetAsync(dev_out, 0, F::NR * sizeof(double), stream));
+            return;
+        }
+        int tx, nt, nb;
+        tiling(r0, r1, ncols, tx, nt, nb);
+        if ((size_t)nb * F::NR > kScratchDoubles) throw std::runtime_error("reduction exceeds the static scratch array");
+        hipLaunchKernelGGL(k_nodes_sum<F>, dim3(nb), dim3(kTileX, kTileY), 0, stream, f, r0, r1, ncols, tx, nt, d_scratch);
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64, F::NR), 0, stream, d_scratch, nb, (int)F::NR, dev_out);
         TEDD_HIP(hipGetLastError());
     }
     // one launch of the register-resident Newton solve chain (tedd_strip.hpp)

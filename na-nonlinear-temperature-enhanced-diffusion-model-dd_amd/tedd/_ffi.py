@@ -81,6 +81,7 @@ PROTOTYPES = {
     "tedd_eval_forcing": (C.c_int, [C.c_void_p, C.c_double] + [_dptr] * 5),
     "tedd_eval_jacobian": (C.c_int, [C.c_void_p, C.c_int32] + [_dptr] * 5),
     "tedd_error_norms": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(_dptr), _dptr]),
+    "tedd_error_norms_noalloc": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),
     "tedd_get_stats": (C.c_int, [C.c_void_p, C.POINTER(TeddStepStats)]),
     "tedd_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "tedd_profile_get": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), _dptr]),
@@ -345,6 +346,10 @@ class Context:
         else:
             self._check(self._lib.tedd_error_norms(self._h, float(t), None, _arr(out)))
         return out
+
+    def error_norms_noalloc(self, t, out_device_ptr):
+        """The 8 error sums into the caller's device memory (an address), without allocating or synchronising."""
+        self._check(self._lib.tedd_error_norms_noalloc(self._h, float(t), C.c_void_p(int(out_device_ptr))))
 
     # -- timing record
     def profile_enable(self, on=True):

@@ -65,6 +65,10 @@ struct CpuBackend {
             for (int j = 0; j < ncols; ++j) f(li, j, red);
         for (int k = 0; k < F::NR; ++k) out[k] = red[k];
     }
+    template <class F>
+    void nodes_sum_noalloc(const F& f, int r0, int r1, int ncols, double* out) {
+        nodes_sum(0, f, r0, r1, ncols, out);
+    }
     template <int CASE, int REACT>
     void correct(const CorrectIn<CASE, REACT>& a, int r0, int r1, int ncols, double* cp_out, double* cs_out, int iters,
                  double rtol, int* keep_out) {
