@@ -6,9 +6,17 @@
 Workload (all ranks together): the ExpSin MMS problem on the synthetic 16384 x 16384-cell mesh
 (4096x the cells of the finest convergence-study mesh, N=256), notebook model constants,
 eta = 50, dt = h^1.5, state = exact solution at t = 0 (generated on the device).  With N > 1 the
-mesh rows are split into N slabs (strong scaling, one ghost-row exchange per step over RCCL).
+mesh rows are split into N slabs, one ghost-row exchange per step over RCCL:
+  --scaling strong (default)  the same 16384^2 mesh for every N; value = steps / second
+  --scaling weak              every rank keeps a 16384-row slab: the domain is [0, N] x [0, 1] with the
+                              same cell size, time step and sweep counts; value = N x steps / second
+                              (time steps of 16384^2-cell slabs per second, all ranks together)
 A "step" is one call of the predictor-corrector integrator (reference
-P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple.step); value = steps / second.
+P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple.step).
+
+`python bench.py --gpus N` with N > 1 launches its own ranks (one process per GPU through
+torch.distributed.run on 127.0.0.1) before anything touches a GPU, relays rank 0's JSON line and exits
+with the launcher's status; started by torch.distributed.run itself (RANK/WORLD_SIZE set) it is a rank.
 
 The JSON line also carries
   roofline      HBM roofline of the kernel family with the largest share of the timed region
@@ -29,6 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "na-nonlinear-temperature-enhanced-diffusi
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (8 TB/s)
+PMC_PROFILE_TAG = "r02"  # prefix of the committed counter summaries that describe the kernels of this tree
 
 NB_A = dict(R0=8.3144621, Ea=1.60217662e-19, K1=1e-3, K2=1e-3, K3=1e-3, K4=1e-3, DT=1e-3,
             Dl_max=1e-5, phi_l=1e-5, gamma_T=1e-9, Kd=1e-2, Sd=1, Dd_max=1e-6, phi_d=1e-5,
@@ -91,7 +100,9 @@ def pmc_traffic(fam, config):
     passes): (2 x FETCH_SIZE + WRITE_SIZE) KB -- on gfx950 FETCH_SIZE tallies the 128-byte requests
     of coalesced streaming reads at 64 bytes.  None if no summary matches the configuration."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{config['mesh_N']}.json")), reverse=True):
+    # only summaries of the kernels of this tree: the counter passes of earlier rounds measured other kernels
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{PMC_PROFILE_TAG}_*pmc_{config['mesh_N']}.json")),
+                       reverse=True):
         with open(path) as fh:
             summ = json.load(fh)
         if any(summ.get("config", {}).get(k) != config[k] for k in ("mesh_N", "solver", "sweeps_per_launch", "forcing")):
@@ -185,7 +196,11 @@ def other_configs_run():
     return out
 
 
-def cpu_baseline_run(N=256, steps=20):
+def _oracle_steps(N, steps, reference_call_counts):
+    """steps/s of the NumPy/SciPy oracle on the N-mesh.  reference_call_counts: evaluate the forcing terms as
+    often as the reference's step does (the cell-averaged fcp and fcs five times, fT, fcl, fcd three times per
+    step, src/prob1base.py:2953-2965, 3117-3149, 3631-3702) and the three Newton residuals, instead of once
+    per time level and no residuals."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import tedd_oracle as orc
     model = orc.Model(NB_A, 2)
@@ -196,23 +211,106 @@ def cpu_baseline_run(N=256, steps=20):
     t0 = time.perf_counter()
     f_prev = pb.forcing(t)
     for _ in range(steps):
-        f_next = pb.forcing(t + dt)
-        S, _ = orc.step_pc(pb, S, t, dt, forcing0=f_prev, forcing1=f_next, want_residual=False)
-        f_prev = f_next
+        if reference_call_counts:
+            for _rep in range(2):           # fT, fcl, fcd: 3 evaluations per step; fcp, fcs: 5
+                pb.forcing(t + dt)
+            for _rep in range(2):
+                orc.forcing_pointwise(pb.case, model, t + dt, pb.mesh.X, pb.mesh.Y, "reg", 50.0, which=("fcs",))
+                orc.cell_average(lambda P, Q: orc.forcing_pointwise(pb.case, model, t + dt, P, Q, "reg", 50.0,
+                                                                    which=("fcp",))["fcp"], pb.mesh)
+            S, _ = orc.step_pc(pb, S, t, dt, want_residual=True)
+        else:
+            f_next = pb.forcing(t + dt)
+            S, _ = orc.step_pc(pb, S, t, dt, forcing0=f_prev, forcing1=f_next, want_residual=False)
+            f_prev = f_next
         t += dt
-    el = time.perf_counter() - t0
-    return {"value": steps / el, "unit": "time-steps/s", "cores": 1, "kind": "port",
+    return steps / (time.perf_counter() - t0)
+
+
+_TWIN_TIMER = r"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from tedd import _ffi
+_ffi.use_library(sys.argv[2])
+N, steps = int(sys.argv[3]), int(sys.argv[4])
+consts = [float(v) for v in sys.argv[5].split(",")]
+x = np.linspace(0, 1, N + 1)
+ctx = _ffi.Context(x, x, consts, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0, mms_case=_ffi.MMS_EXPSIN)
+dt = (1.0 / N) ** 1.5
+ctx.set_state_exact(0.0)
+ctx.advance(0.0, dt, 1, want_errors=False)
+t0 = time.perf_counter()
+ctx.advance(dt, dt, steps, want_errors=False)
+print(steps / (time.perf_counter() - t0))
+"""
+
+
+def _twin_steps(N, steps, threads):
+    """steps/s of the host-compiled twin of the device source (tests/cpu_twin: the same node functors and step
+    sequencing under a loop backend, Jacobi solves, OpenMP over the rows) in a child process that never touches
+    the GPU, with `threads` OpenMP threads.  None if the twin library is not there."""
+    import subprocess
+    twin = os.path.join(ROOT, "tests", "cpu_twin", "libtedd_twin.so")
+    if not os.path.exists(twin):
+        return None
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false")
+    pkg = os.path.join(ROOT, "na-nonlinear-temperature-enhanced-diffusion-model-dd_amd")
+    r = subprocess.run([sys.executable, "-c", _TWIN_TIMER, pkg, twin, str(N), str(steps),
+                        ",".join(repr(float(NB_A[k])) for k in CONST_KEYS)],
+                       capture_output=True, text=True, env=env, timeout=120)
+    if r.returncode != 0:
+        return None
+    return float(r.stdout.strip().splitlines()[-1])
+
+
+CONST_KEYS = ("R0", "Ea", "K1", "K2", "K3", "K4", "DT", "Dl_max", "phi_l", "gamma_T", "Kd", "Sd", "Dd_max",
+              "phi_d", "phi_T", "r_sp", "T_ref")
+
+
+def cpu_baseline_run(N=256, steps=5):
+    """The CPU side of the comparison on the host cores of this box, on a bounded sample (a few seconds in all).
+    `value` is the NumPy/SciPy oracle with the forcing evaluated once per time level (the fastest honest
+    single-process NumPy/SciPy form of the reference's algorithm); `variants` adds the same oracle with the
+    reference's call counts, and the host-compiled C++ twin on one core and on all cores of this GPU's share."""
+    cores_all = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+    v = _oracle_steps(N, steps, False)
+    variants = {
+        "numpy_scipy_port": {"steps_per_s": v, "cores": 1, "steps": steps,
+                             "what": "oracle/tedd_oracle.py, spsolve, forcing once per time level, no residuals"},
+        "numpy_scipy_port_reference_call_counts": {
+            "steps_per_s": _oracle_steps(N, max(2, steps // 2), True), "cores": 1, "steps": max(2, steps // 2),
+            "what": "the same with the forcing terms evaluated as often as the reference's step does and the Newton "
+                    "residuals computed (the reference's per-call Grid() reconstruction is not reproduced)"},
+    }
+    for name, th in (("cpp_twin_1_core", 1), ("cpp_twin_all_cores", cores_all)):
+        r = _twin_steps(N, 40 if th == 1 else 200, th)
+        if r is not None:
+            variants[name] = {"steps_per_s": r, "cores": th, "steps": 40 if th == 1 else 200,
+                              "what": "tests/cpu_twin: the device source compiled for the host (g++ -O2 -fopenmp), "
+                                      "Jacobi solves"}
+    return {"value": v, "unit": "time-steps/s", "cores": 1, "kind": "port",
             "sample": f"{steps} predictor-corrector steps of ExpSin on the N={N} mesh (finest convergence-study "
-                      f"mesh) with the NumPy/SciPy oracle (spsolve), forcing evaluated once per time level"}
+                      f"mesh) with the NumPy/SciPy oracle (spsolve), forcing evaluated once per time level",
+            "host_cpu_count": os.cpu_count(), "omp_num_threads_env": os.environ.get("OMP_NUM_THREADS"),
+            "variants": variants}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mesh", type=int, default=16384, help="N of the (N+1)^2-node synthetic mesh")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong: one N x N mesh split over the ranks; weak: an N-row slab per rank")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for CPU rehearsals)")
+    ap.add_argument("--device", choices=["cuda", "cpu"], default="cuda",
+                    help="cpu: drive a host-compiled library given with --library (rehearsal of the multi-rank path)")
+    ap.add_argument("--library", default=None, help="path of the C-ABI library (default: the HIP build)")
     ap.add_argument("--jacobi-tol", type=float, default=1e-13)
+    ap.add_argument("--fixed-sweeps", action="store_true",
+                    help="fix the Jacobi sweep counts at the a-priori bound instead of the library's stopping rule")
     ap.add_argument("--no-extras", action="store_true", help="skip the N=256 study-mesh and CPU-baseline legs")
     ap.add_argument("--solver", choices=["strip", "sweeps"], default="strip",
                     help="Newton solve: register-resident chain | one launch per Jacobi sweep")
@@ -223,7 +321,31 @@ def main():
                     help="with --cache-forcing 1: the predictor launch evaluates the forcing arrays of t1 itself "
                          "(-1: the library's rule, slabs of at most 4 M nodes)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (repeatable)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child launcher (nothing
+    in this process has touched a GPU or imported torch), pass its output through and return its status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -234,22 +356,35 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    on_gpu = args.device == "cuda"
+    if args.library:
+        _ffi.use_library(args.library)
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if on_gpu and args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
+    ranks_seen = dist.get_world_size() if world > 1 else 1
+    backend_name = dist.get_backend() if world > 1 else None
 
     N = args.mesh
+    weak = args.scaling == "weak"
+    rows_global = (N * world if weak else N) + 1     # weak: the domain grows along x with the ranks, same cell size
     dt = (1.0 / N) ** 1.5
-    sweeps = pick_sweeps(N, dt, args.jacobi_tol)
-    ghost = sum(sweeps) + 3
-    slab = partition_rows(N + 1, world, rank, ghost)
-    x = np.linspace(0, 1, N + 1)
-    ctx = _ffi.Context(x, x, consts_vec(NB_A), model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+    sweeps_cap = pick_sweeps(N, dt, args.jacobi_tol)  # a-priori counts: size the ghost zone; the library's
+    ghost = sum(sweeps_cap) + 3                      # stopping rule never asks for more unless it reports it
+    slab = partition_rows(rows_global, world, rank, ghost)
+    x = np.linspace(0.0, float(world) if weak else 1.0, rows_global)
+    y = np.linspace(0.0, 1.0, N + 1)
+    ctx = _ffi.Context(x, y, consts_vec(NB_A), model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
                        mms_case=_ffi.MMS_EXPSIN, row_lo=slab.row_lo, row_hi=slab.row_hi, ghost=slab.ghost,
-                       device=local_rank)
+                       device=local_rank if on_gpu else -1)
     stepper = SlabStepper(ctx, slab, device)
     ctx.set_option("strip_solve", 1 if args.solver == "strip" else 0)
     ctx.set_option("cache_forcing", args.cache_forcing)
@@ -261,13 +396,17 @@ def main():
         name, value = kv.split("=")
         ctx.set_option(name, float(value))
     ctx.set_state_exact(0.0)
-    kw = dict(jacobi_sweeps=sweeps, jacobi_tol=args.jacobi_tol)
+    kw = dict(jacobi_sweeps=sweeps_cap if args.fixed_sweeps else None, jacobi_tol=args.jacobi_tol)
 
     def barrier():
-        torch.cuda.synchronize(device)
+        if on_gpu:
+            torch.cuda.synchronize(device)
+        else:
+            ctx.sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        if on_gpu:
+            torch.cuda.synchronize(device)
 
     t = 0.0
     for _ in range(args.warmup):
@@ -284,6 +423,8 @@ def main():
     prof = ctx.profile_get()
     ctx.profile_enable(False)
     stats = ctx.get_stats()
+    stepper.check_converged()
+    sweeps = stats["sweeps"]
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -316,27 +457,36 @@ def main():
                    "share": v["total_ms"] / (1e3 * elapsed), "GBps": gbps(k)} for k, v in prof.items()}
     # arrays per step = sum over the launches the step actually made
     arrays_step = sum(arrays.get(k, 0) * v["launches"] for k, v in prof.items()) / args.steps
-    step_gbs = 8.0 * (N + 1) * (N + 1) * arrays_step * args.steps / elapsed / 1e9
+    nodes_all = rows_global * (N + 1)
+    step_gbs = 8.0 * nodes_all * arrays_step * args.steps / elapsed / 1e9
 
     forcing_mode = ("closed form inside the step kernels" if not args.cache_forcing else
                     "arrays per time level, made by the predictor launch" if args.fuse_forcing else "arrays per time level")
-    cfg_key = {"mesh_N": N, "solver": args.solver, "sweeps_per_launch": args.hmax, "forcing": forcing_mode}
+    cfg_key = {"mesh_N": N, "solver": args.solver, "sweeps_per_launch": args.hmax, "forcing": forcing_mode,
+               "jacobi_sweeps": list(sweeps)}
     if roofline is not None and world == 1:   # the committed counter passes are whole-mesh launches on one GPU
         tr = pmc_traffic(fam, cfg_key)
         if tr is not None:
             roofline["traffic"] = tr["bytes_per_launch"]
             roofline["traffic_source"] = tr["source"]
             roofline["algorithmic_bytes_per_launch"] = 8.0 * n_nodes_local * arrays.get(fam, 0)
+    units = args.steps * (world if weak else 1)
+    mesh_txt = (f"{rows_global - 1}x{N}-cell mesh on [0,{world}]x[0,1] ({nodes_all} nodes, a {N}-row slab per rank)"
+                if weak else f"{N}x{N}-cell mesh ({nodes_all} nodes)")
     out = {
         "metric": "time-steps/sec, MMSCaseExpSin predictor-corrector (reghcstriple), synthetic 4096x mesh",
-        "value": args.steps / elapsed, "unit": "time-steps/s", "n_gpus": world, "steps": args.steps,
+        "value": units / elapsed, "unit": "time-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"MMSCaseExpSin reghcstriple, {N}x{N}-cell mesh ({(N + 1) ** 2} nodes), dt=h^1.5, "
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "ranks_seen": ranks_seen, "backend": backend_name,
+        "config": {"workload": f"MMSCaseExpSin reghcstriple, {mesh_txt}, dt=h^1.5, "
                                f"eta=50, notebook model constants, 1 PC x 1 Newton step, 5 cs-Newton iterations",
-                   "mesh_N": N, "jacobi_sweeps": sweeps, "jacobi_tol": args.jacobi_tol,
+                   "mesh_N": N, "jacobi_sweeps": list(sweeps), "jacobi_sweeps_a_priori": sweeps_cap,
+                   "jacobi_tol": args.jacobi_tol,
                    "solver": args.solver, "sweeps_per_launch": args.hmax, "solve_chains": chains,
                    "forcing": forcing_mode,
+                   "value_counts": ("time steps of the whole mesh" if not weak else
+                                    "time steps of one rank's slab, summed over the ranks"),
                    "parallelism": f"row slabs x{world}, ghost={slab.ghost}", "error_H_after_run": err_H},
         "roofline": roofline,
         "step_hbm": {"algorithmic_arrays_per_step": arrays_step, "achieved_GBps_all_gpus": step_gbs,
@@ -345,7 +495,7 @@ def main():
         "jacobi_last_update": stats["last_update"], "jacobi_increment": stats["increment"],
     }
     ctx.close()
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and on_gpu and not args.no_extras:
         sm = study_mesh_run()
         cb = cpu_baseline_run()
         sm["speedup_vs_cpu_baseline"] = sm["steps_per_s"] / cb["value"]
@@ -353,7 +503,7 @@ def main():
         out["cpu_baseline"] = cb
         out["other_configs"] = other_configs_run()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -34,7 +34,7 @@ enum tedd_status {
     TEDD_ERR_INVALID = -1,     /* bad argument (maps to ValueError) */
     TEDD_ERR_ASSERT = -2,      /* a precondition the reference asserts (dt > 0, shapes): AssertionError */
     TEDD_ERR_RUNTIME = -3,     /* HIP failure, out of memory, unsupported configuration: RuntimeError */
-    TEDD_ERR_NOT_CONVERGED = -4 /* a Jacobi solve missed its tolerance within jacobi_max sweeps */
+    TEDD_ERR_NOT_CONVERGED = -4 /* a Jacobi solve missed its tolerance (tedd_check_converged, tedd_advance) */
 };
 
 enum tedd_mms_case {
@@ -102,7 +102,9 @@ int tedd_set_mms_program(tedd_ctx* ctx, int32_t which, const uint32_t* code, int
  * of 4 strips, 1: 32-row tiles of 8 short strips for meshes too small to fill the GPU, 2: 48-row tiles of 12
  * short strips); "cache_forcing" (default 1): evaluate the closed-form MMS
  * forcing once per time level into arrays instead of inside the step kernels; "fuse_forcing" (default -1:
- * slabs of at most 4 M nodes): those arrays are made by the predictor launch instead of a launch of their own. */
+ * slabs of at most 4 M nodes): those arrays are made by the predictor launch instead of a launch of their own;
+ * "warm_start" (default 1): a Newton solve whose sweep count the library chooses starts its Jacobi iteration
+ * from the increment of the step before instead of zero (same tolerance, fewer sweeps). */
 int tedd_set_option(tedd_ctx* ctx, const char* name, double value);
 /* Use the caller's HIP stream (hipStream_t passed as void*) for all subsequent work. */
 int tedd_set_stream(tedd_ctx* ctx, void* hip_stream);
@@ -138,9 +140,11 @@ int tedd_prefetch_forcing(tedd_ctx* ctx, double t, double keep_t);
 /* One predictor-corrector step of P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_{RegHCsTriple,CsTriple}
  * (src/prob1base.py:3117-3149 with 2953-3115, 3174-3219, 3631-3702).  The 5-diagonal systems the
  * reference solves with spsolve (src/prob1base.py:2103,2130) are solved by matrix-free Jacobi
- * sweeps: jacobi_sweeps[v] > 0 fixes the sweep count for v = T, cl, cd; <= 0 picks it from the
- * contraction bound of the system so that the last update is below jacobi_tol relative to the
- * solution increment (capped at jacobi_max).  jacobi_sweeps may be NULL (all automatic). */
+ * sweeps: jacobi_sweeps[v] > 0 fixes the sweep count for v = T, cl, cd (from a zero iterate); <= 0 lets the
+ * library choose it so that the last update is below jacobi_tol relative to the solution increment (capped at
+ * jacobi_max): from the contraction bound of the system and, in a run of consecutive steps, from the
+ * convergence record of the step two before (the iteration then starts from the last step's increment).
+ * Solves with a chosen count are judged afterwards (tedd_check_converged).  jacobi_sweeps may be NULL. */
 int tedd_step_pc(tedd_ctx* ctx, double t0, double dt, int32_t num_pc_steps, int32_t num_newton_steps,
                  int32_t cs_newton_iterations, double cs_consec_xs_rtol, const int32_t jacobi_sweeps[3],
                  double jacobi_tol, int32_t jacobi_max);
@@ -206,14 +210,41 @@ int tedd_error_norms_noalloc(tedd_ctx* ctx, double t, double* out_device);
 
 /* Record of the last step: sweeps[3] Jacobi sweeps used for T, cl, cd; last_update[3] and
  * increment[3]: max-norms of the last sweep's update and of the solution increment;
- * cs_iterations: Newton iterations the cs corrector kept (global early exit, src/prob1base.py:3661). */
+ * cs_iterations: Newton iterations the cs corrector kept (global early exit, src/prob1base.py:3661);
+ * warm_started[v]: that solve started from the increment of the step before instead of zero, and
+ * first_update[v] is the max-norm of its first sweep's update; worst_ratio[v]: the largest
+ * last_update / (jacobi_tol x increment) over the steps since the last tedd_check_converged, counting only
+ * solves whose sweep count the library chose. */
 typedef struct tedd_step_stats {
     int32_t sweeps[3];
     int32_t cs_iterations;
     double last_update[3];
     double increment[3];
+    int32_t warm_started[3];
+    int32_t reserved;
+    double first_update[3];
+    double worst_ratio[3];
 } tedd_step_stats;
 int tedd_get_stats(tedd_ctx* ctx, tedd_step_stats* out);
+
+/* The reference solves its Newton systems directly (spsolve, src/prob1base.py:2103,2130), which cannot stop
+ * short; Jacobi sweeps can.  Every solve whose sweep count the library chose is therefore judged on the
+ * device after the fact (last update <= jacobi_tol x increment) and the worst ratio of all steps is kept.
+ * tedd_check_converged returns TEDD_ERR_NOT_CONVERGED if some step since the last check missed its tolerance by
+ * more than a factor 10, and clears the record.  tedd_advance performs this check before it returns; callers
+ * that step with tedd_step_pc call it at their own synchronisation points (it synchronises the stream). */
+int tedd_check_converged(tedd_ctx* ctx);
+
+/* Reduction across the slabs of a decomposed mesh.  The reference decides the early exit of the cs corrector's
+ * Newton iteration from maxima and minima over ALL nodes (src/prob1base.py:3661); a context sees its own rows
+ * only.  With a hook set, the context calls it (on the calling thread, inside tedd_step_pc /
+ * tedd_correct_cp_cs) between the pass that records, per iteration k, dev_max[k] = max|dx_k| and
+ * dev_min[k] = min|x_k| over its rows and the pass that acts on them; the hook must replace dev_max[k] by the
+ * maximum and dev_min[k] by the minimum over all slabs (n values each, device memory of this context), by work
+ * ordered on the context's stream, and return 0 (anything else fails the step with TEDD_ERR_RUNTIME).
+ * fn = NULL removes the hook. */
+typedef int (*tedd_reduce_fn)(void* user, double* dev_max, double* dev_min, int32_t n);
+int tedd_set_reduce_hook(tedd_ctx* ctx, tedd_reduce_fn fn, void* user);
 
 /* Per-kernel device timing with HIP events on the context's stream.  enable != 0 starts
  * recording (and clears the totals).  tedd_profile_get returns, for up to `cap` kernel families,

@@ -237,6 +237,12 @@ int tedd_get_stats(tedd_ctx* ctx, tedd_step_stats* out) {
         C.get_stats(out);
     });
 }
+int tedd_check_converged(tedd_ctx* ctx) {
+    return guarded(ctx, [&](auto& C) { C.check_converged(); });
+}
+int tedd_set_reduce_hook(tedd_ctx* ctx, tedd_reduce_fn fn, void* user) {
+    return guarded(ctx, [&](auto& C) { C.set_reduce_hook(fn, user); });
+}
 int tedd_profile_enable(tedd_ctx* ctx, int32_t enable) {
     return guarded(ctx, [&](auto& C) { C.be.profile_enable(enable != 0); });
 }

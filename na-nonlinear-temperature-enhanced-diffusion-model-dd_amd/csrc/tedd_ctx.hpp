@@ -9,6 +9,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -78,7 +79,32 @@ public:
     std::map<const double*, Range> valid;
 
     // small device scratch: reductions and records
-    double* d_red = nullptr;      // 64 doubles
+    double* d_red = nullptr;      // 64 doubles: [0..15] convergence record of the step in flight, [16..18] sticky
+                                  // worst ratios (see StepRecordArgs), [32..39] error norms
+    // History of the convergence records.  Every predictor-corrector step has a sequence number that is
+    // never reused; the prologue launch of step g+1 publishes the record of step g to ring slot g % kRing
+    // (host-visible memory), and step g+2 reads it there to choose its sweep counts -- by then the
+    // prologue of step g+1 has run unless the host is more than a step ahead of the GPU, in which case
+    // it waits for that one small launch, never for a step.
+    static constexpr int kRing = 8;
+    double* h_ring = nullptr;     // kRing x 16 doubles, host-visible
+    double* d_ring = nullptr;     // the same memory as the device addresses it
+    struct StepMeta {
+        long long seq = -1;
+        int sweeps[3] = {0, 0, 0};
+        bool warm[3] = {false, false, false};
+        double tol[3] = {0, 0, 0};  // > 0: the library chose the sweeps of that system (its record is judged)
+        double rho[3] = {0, 0, 0};  // a-priori contraction bound the choice was made with
+    } meta[kRing];
+    long long next_seq = 0;       // sequence number of the next predictor-corrector step
+    long long chain_start = 0;    // first sequence number of the present run of consecutive steps
+    bool record_unfolded = false; // step next_seq-1 left a record that has not been published to the ring
+    bool record_unjudged = false; // ... and has not been folded into the sticky ratios
+    bool judged_since_check = false;
+    // T, cl, cd of the time level before the current state (warm start of the Newton solves)
+    double* prev[3] = {nullptr, nullptr, nullptr};
+    double prev_dt = 0.0;
+    int opt_warm = 1;             // start the Jacobi iteration from the increment of the step before
     double* d_series = nullptr;   // error-norm series of tedd_advance
     size_t series_cap = 0;
     int* d_ints = nullptr;        // [0] cs iterations kept, [1] HCsTriple corrector: denominator not positive
@@ -153,6 +179,9 @@ public:
         d_ints = (int*)be.alloc(16 * sizeof(int));
         be.memset0(d_red, 64 * sizeof(double));
         be.memset0(d_ints, 16 * sizeof(int));
+        h_ring = (double*)be.alloc_host_visible((size_t)kRing * 16 * sizeof(double));
+        d_ring = (double*)be.device_view(h_ring);
+        for (int k = 0; k < kRing; ++k) h_ring[16 * k] = -1.0;
         for (int v = 0; v < 5; ++v) cur[v] = nullptr;
     }
     ~Ctx() {
@@ -175,6 +204,8 @@ public:
         be.free(d_red);
         be.free(d_series);
         be.free(d_ints);
+        be.sync_quiet();  // a prologue launch may still be writing the ring
+        be.free_host_visible(h_ring);
         be.shutdown();
     }
 
@@ -442,6 +473,8 @@ public:
         if (!p) return;
         for (int v = 0; v < 5; ++v)
             if (cur[v] == p) return;
+        for (int v = 0; v < 3; ++v)
+            if (prev[v] == p) return;
         if (std::find(free_bufs.begin(), free_bufs.end(), p) == free_bufs.end()) free_bufs.push_back(p);
     }
     void release_retained() {
@@ -489,10 +522,20 @@ public:
     void require_state() const {
         if (!cur[0]) throw InvalidError("state not set");
     }
+    void drop_prev() {
+        for (int v = 0; v < 3; ++v) {
+            double* p = prev[v];
+            prev[v] = nullptr;
+            release(p);
+        }
+        prev_dt = 0.0;
+    }
     void reset_history() {
         fcp_time[0] = fcp_time[1] = NAN;
         last.have = false;
         release_retained();
+        drop_prev();
+        chain_start = next_seq;  // records of steps before this point say nothing about the new state
     }
     void ensure_state_buffers() {
         for (int v = 0; v < 5; ++v)
@@ -508,7 +551,7 @@ public:
         be.d2h_fields(h, cur, 5, ld, ncols, nrows);
     }
     // Install nxt as the state; buffers of the old state that are not reused go back to the pool.
-    void commit_state(double* const nxt[5]) {
+    void commit_state(double* const nxt[5], bool keep_old_as_prev = false, double dt = 0.0) {
         Range o = owned();
         for (int v = 0; v < 5; ++v) {
             Range r = vof(nxt[v]);
@@ -520,6 +563,15 @@ public:
             old[v] = cur[v];
             cur[v] = nxt[v];
         }
+        double* gone[3] = {prev[0], prev[1], prev[2]};
+        for (int v = 0; v < 3; ++v) prev[v] = nullptr;
+        if (keep_old_as_prev && opt_warm) {
+            for (int v = 0; v < 3; ++v) prev[v] = (old[VAR_T + v] != cur[VAR_T + v]) ? old[VAR_T + v] : nullptr;
+            prev_dt = dt;
+        } else {
+            prev_dt = 0.0;
+        }
+        for (int v = 0; v < 3; ++v) release(gone[v]);
         for (int v = 0; v < 5; ++v) release(old[v]);
     }
     // The caller refreshed the ghost rows of the current state (halo exchange).
@@ -789,6 +841,8 @@ public:
         int num_pc, num_newton, cs_iters;
         double cs_rtol;
         int sweeps[3];
+        bool warm[3] = {false, false, false};  // start the first Newton solve of v from the last increment
+        double gscale = 0.0;                   // dt / dt of the step before
     };
     struct PcOp {
         Ctx* c;
@@ -799,6 +853,92 @@ public:
         }
     };
 
+    // The record the prologue of step `seq + 1` published for step `seq`: waits (bounded) until it is there.
+    // Returns false if the record cannot be had (never published, or overwritten).
+    bool lagged_record(long long seq, double* upd, double* inc, double* first) {
+        if (seq < chain_start || seq < 0 || seq + kRing <= next_seq || seq + 1 >= next_seq) return false;
+        volatile double* slot = h_ring + 16 * (seq % kRing);
+        const double want = (double)seq;
+        for (long long spin = 0; slot[0] != want; ++spin) {
+            if (spin == (1LL << 22)) be.sync();  // (the prologue that publishes it has long been enqueued)
+            if (spin > (1LL << 22) + 16) return false;
+        }
+        for (int v = 0; v < 3; ++v) {
+            upd[v] = slot[1 + v];
+            inc[v] = slot[4 + v];
+            first[v] = slot[7 + v];
+        }
+        return slot[0] == want;
+    }
+
+    // Sweep counts of the three Newton solves.  A count the caller fixes is used as it is, from a zero
+    // iterate.  Otherwise: rows of (2 I - dt J) are diagonally dominant with contraction rho <= q / (2 + q)
+    // per Jacobi sweep; from a zero iterate ceil(log tol / log rho) + 1 sweeps bring the last update below
+    // tol x increment.  With the state of the step before at hand the iteration starts from that step's
+    // increment instead (the increments of consecutive steps differ by O(dt)), and the count follows from
+    // the first update max|delta^1 - delta^0| / max|delta| that the step two before this one recorded for
+    // its own warm start (with a factor 4 of margin), never more than the cold count plus one.  The record
+    // also carries the contraction actually seen, which replaces the bound where it is worse.
+    void choose_sweeps(StepParams& p, const int32_t* sweeps_in, double jtol, int jmax, StepMeta& mt) {
+        const double dcoef[3] = {model.DT, model.Dl_max, model.Dd_max};
+        const bool partial = (gl > 0 || gr > 0);
+        const bool can_warm = opt_warm && p.num_pc > 0 && p.num_newton > 0 && prev_dt > 0.0 && next_seq > chain_start;
+        double upd[3], inc[3], first[3];
+        bool have_rec = false;
+        bool asked = false;
+        p.gscale = can_warm ? p.dt / prev_dt : 0.0;
+        for (int v = 0; v < 3; ++v) {
+            const int s_in = sweeps_in ? sweeps_in[v] : 0;
+            mt.warm[v] = false;
+            mt.tol[v] = 0.0;
+            mt.rho[v] = 0.0;
+            if (s_in > 0) {
+                p.sweeps[v] = std::max(2, (int)s_in);
+                mt.sweeps[v] = p.sweeps[v];
+                continue;
+            }
+            const double q = p.dt * std::fabs(dcoef[v]) * q_metric;
+            double rho = (q > 0) ? q / (2.0 + q) : 0.0;
+            const int cold = auto_sweeps(q, jtol, jmax);
+            int s = cold;
+            bool warm = false;
+            mt.tol[v] = jtol;
+            if (can_warm && prev[v]) {
+                warm = true;
+                s = std::min(cold + (partial ? 0 : 1), jmax);  // until a record says how good the start is
+                if (!asked) {
+                    have_rec = lagged_record(next_seq - 2, upd, inc, first);
+                    asked = true;
+                }
+                const StepMeta& m2 = meta[(next_seq - 2 + 2 * kRing) % kRing];
+                if (have_rec && m2.seq == next_seq - 2 && m2.warm[v] && inc[v] > 0.0 && first[v] == first[v] &&
+                    upd[v] == upd[v]) {
+                    // contraction seen two steps ago, where the record can tell: a last update within a
+                    // factor 100 of the rounding of the iterate (2^-53 x increment) is noise, not convergence
+                    if (m2.sweeps[v] >= 3 && first[v] > 0.0 && upd[v] > 1e-14 * inc[v]) {
+                        const double seen = std::pow(upd[v] / first[v], 1.0 / (m2.sweeps[v] - 1));
+                        if (seen > rho && seen < 1.0) rho = seen;
+                    }
+                    // sweeps after the first so that the last update is below tol / 4 (the start of this
+                    // step is judged by that of the step two before: the factor covers the difference)
+                    const double r0 = 4.0 * first[v] / inc[v];
+                    if (r0 <= jtol || rho <= 0.0) {
+                        s = 2;
+                    } else if (rho < 1.0) {
+                        const double want = 1.0 + std::max(std::ceil(std::log(jtol / r0) / std::log(rho)), 0.0);
+                        if (want < (double)s) s = (int)want;
+                    }
+                    if (s < 2) s = 2;
+                }
+            }
+            p.sweeps[v] = s;
+            p.warm[v] = warm;
+            mt.sweeps[v] = s;
+            mt.warm[v] = warm;
+            mt.rho[v] = rho;
+        }
+    }
+
     void step_pc(double t0, double dt, int num_pc, int num_newton, int cs_iters, double cs_rtol,
                  const int32_t* sweeps_in, double jtol, int jmax) {
         require_state();
@@ -808,11 +948,44 @@ public:
         if (!(jtol > 0)) jtol = 1e-13;
         if (jmax < 2) jmax = 2;
         StepParams p{t0, dt, num_pc, num_newton, cs_iters, cs_rtol, {0, 0, 0}};
-        const double dcoef[3] = {model.DT, model.Dl_max, model.Dd_max};
-        for (int v = 0; v < 3; ++v) {
-            const int s = sweeps_in ? sweeps_in[v] : 0;
-            p.sweeps[v] = (s > 0) ? std::max(2, (int)s) : auto_sweeps(dt * std::fabs(dcoef[v]) * q_metric, jtol, jmax);
+        StepMeta mt;
+        mt.seq = next_seq;
+        choose_sweeps(p, sweeps_in, jtol, jmax, mt);
+        // prologue: fold and publish the record of the step before, clear the records of this one
+        {
+            StepRecordArgs ra;
+            ra.red = d_red;
+            const bool have_before = next_seq > chain_start && record_unfolded;
+            const StepMeta& mb = meta[(next_seq - 1 + kRing) % kRing];
+            ra.fold = (have_before && record_unjudged) ? 1 : 0;
+            ra.ring_slot = have_before ? d_ring + 16 * ((next_seq - 1) % kRing) : nullptr;
+            ra.seq = (double)(next_seq - 1);
+            for (int v = 0; v < 3; ++v) ra.tol[v] = have_before ? mb.tol[v] : 0.0;
+            ra.clear = 1;
+            ra.cs_iters = (react == REACT_REG) ? cs_iters : 0;
+            be.step_prologue(ra);
         }
+        meta[next_seq % kRing] = mt;
+        next_seq += 1;
+        record_unfolded = (num_pc > 0 && num_newton > 0);
+        record_unjudged = record_unfolded;
+        for (int v = 0; v < 3; ++v) judged_since_check = judged_since_check || (record_unfolded && mt.tol[v] > 0.0);
+        try {
+            step_pc_dispatch(p);
+        } catch (...) {
+            // nothing of a failed step may serve a later one
+            bT_ready = false;
+            predict_makes_f1 = false;
+            fset_time[0] = fset_time[1] = NAN;
+            fcp_time[0] = fcp_time[1] = NAN;
+            record_unfolded = record_unjudged = false;
+            chain_start = next_seq;
+            drop_prev();
+            throw;
+        }
+    }
+    void step_pc_dispatch(const StepParams& p) {
+        const double t0 = p.t0, dt = p.dt;
         PcOp op{this, p};
         if ((opt_cache_forcing || mms_case == CASE_PROG) && mms_case != CASE_STREAM) {
             // evaluate the closed-form forcing once per time level, then run the array-fed kernels
@@ -844,6 +1017,45 @@ public:
             return;
         }
         dispatch(op);
+    }
+    // Fold the record of the last step into the sticky ratios now (idempotent: a maximum).
+    void fold_last_record() {
+        if (!record_unjudged || next_seq <= chain_start) return;
+        StepRecordArgs ra;
+        ra.red = d_red;
+        ra.ring_slot = nullptr;
+        ra.seq = 0.0;
+        const StepMeta& mb = meta[(next_seq - 1 + kRing) % kRing];
+        for (int v = 0; v < 3; ++v) ra.tol[v] = mb.tol[v];
+        ra.fold = 1;
+        ra.clear = 0;
+        ra.cs_iters = 0;
+        be.step_prologue(ra);
+        record_unjudged = false;
+    }
+    // The reference solves its Newton systems exactly (src/prob1base.py:2103,2130); here every solve whose
+    // sweep count the library chose is judged after the fact: last update <= tol x increment.  Throws
+    // NotConverged if some step since the last check missed that by more than a factor 10, and clears the
+    // sticky record either way.
+    void check_converged() {
+        if (!judged_since_check) return;
+        fold_last_record();
+        double worst[3];
+        be.d2h(worst, d_red + 16, 3 * sizeof(double));
+        be.sync();
+        be.memset0(d_red + 16, 3 * sizeof(double));
+        judged_since_check = false;
+        static const char* nm[3] = {"T", "cl", "cd"};
+        for (int v = 0; v < 3; ++v) {
+            if (worst[v] > 10.0 || worst[v] != worst[v]) {
+                char buf[256];
+                std::snprintf(buf, sizeof buf,
+                              "the Jacobi solve of the %s system missed its tolerance: last update / (tol x increment) "
+                              "reached %.3g in some step; fix the sweep counts (jacobi_sweeps) or raise jacobi_max",
+                              nm[v], worst[v]);
+                throw NotConverged(buf);
+            }
+        }
     }
     // Evaluate the forcing arrays of a coming time level now, into the set that does not hold
     // `keep_t` (the level the next step starts from).  The forcing does not depend on the state, so a
@@ -889,11 +1101,13 @@ public:
     // then ceil((nsweeps-1)/hmax) launches that iterate on (b, delta).
     template <int VAR, int CASE, int REACT>
     void newton_solve_strip(const StepParams& p, const ForcingSrc& f1, const NewtonIn& a, double* unew, int nsweeps,
-                            int slot_id) {
+                            int slot_id, const double* u_prev) {
         if constexpr (Backend::kHasStripSolve) {
             const int fam = (VAR == VAR_T) ? FAM_SOLVE_T : (VAR == VAR_CL) ? FAM_SOLVE_CL : FAM_SOLVE_CD;
             const int fam_rhs = (VAR == VAR_T) ? FAM_RHS_T : (VAR == VAR_CL) ? FAM_RHS_CL : FAM_RHS_CD;
-            int remaining = nsweeps - 1;
+            // from a zero iterate the node kernel's b = rhs/diag is the first sweep already; a warm start
+            // performs all of them here
+            int remaining = u_prev ? nsweeps : nsweeps - 1;
             // up to 10 sweeps per launch: measured best at 16384^2 (two launches of 10 + 9 for the T
             // system beat three of 7 + 6 + 6 although the column halo is then no longer line-aligned)
             int hmax = opt_strip_hmax > 0 ? opt_strip_hmax : 10;
@@ -923,20 +1137,28 @@ public:
                 be.nodes(fam_rhs, fr, r.lo, r.hi, ncols);
                 mark(bsc, r);
             }
-            const double* din = bsc;
+            const double* din = u_prev ? nullptr : bsc;
+            const double* uo = (VAR == VAR_T) ? a.To : (VAR == VAR_CL) ? a.clo : a.cdo;
             for (int l = 0; l < L; ++l) {
                 const int ns = (remaining + (L - l) - 1) / (L - l);
                 remaining -= ns;
                 const bool lastl = (l == L - 1);
+                const bool warm_first = (u_prev != nullptr && l == 0);
                 A.H = ns;
                 A.nsweeps = ns;
+                A.u_prev = warm_first ? u_prev : nullptr;
+                A.gscale = warm_first ? p.gscale : 0.0;
+                A.stats_first = warm_first ? reinterpret_cast<unsigned long long*>(d_red + 8 + 2 * slot_id) : nullptr;
+                // (the starting iterate of a warm chain is made of the lagged unknown and u_prev)
+                const double* s0 = warm_first ? uo : din;
+                const double* s1 = warm_first ? u_prev : nullptr;
                 if (VAR == VAR_T)
-                    r = need_depth({{a.cp1, false}, {bsc, false}, {din, false}}, ns);
+                    r = need_depth({{a.cp1, false}, {bsc, false}, {s0, false}, {s1, false}}, ns);
                 else if (VAR == VAR_CL)
-                    r = need_depth({{a.cp1, true}, {a.To, true}, {bsc, false}, {din, false}}, ns);
+                    r = need_depth({{a.cp1, true}, {a.To, true}, {bsc, false}, {s0, false}, {s1, false}}, ns);
                 else
                     r = need_depth({{a.cp1, true}, {a.To, true}, {a.clo, false}, {a.cs1, false}, {bsc, false},
-                                    {din, false}}, ns);
+                                    {s0, false}, {s1, false}}, ns);
                 A.r0 = r.lo;
                 A.r1 = r.hi;
                 A.b_in = bsc;
@@ -957,10 +1179,11 @@ public:
     }
 
     template <int VAR, int CASE, int REACT>
-    void newton_solve(const StepParams& p, const ForcingSrc& f1, const NewtonIn& a, double* unew, int nsweeps, int slot_id) {
+    void newton_solve(const StepParams& p, const ForcingSrc& f1, const NewtonIn& a, double* unew, int nsweeps, int slot_id,
+                      const double* u_prev = nullptr) {
         if constexpr (Backend::kHasStripSolve) {
             if (opt_strip) {
-                newton_solve_strip<VAR, CASE, REACT>(p, f1, a, unew, nsweeps, slot_id);
+                newton_solve_strip<VAR, CASE, REACT>(p, f1, a, unew, nsweeps, slot_id, u_prev);
                 return;
             }
         }
@@ -970,6 +1193,7 @@ public:
         double* db = B(DB);
         const int fam_rhs = (VAR == VAR_T) ? FAM_RHS_T : (VAR == VAR_CL) ? FAM_RHS_CL : FAM_RHS_CD;
         const int fam_jac = (VAR == VAR_T) ? FAM_JACOBI_T : (VAR == VAR_CL) ? FAM_JACOBI_CL : FAM_JACOBI_CD;
+        const double* uo = (VAR == VAR_T) ? a.To : (VAR == VAR_CL) ? a.clo : a.cdo;
         Range r;
         if (VAR == VAR_T)
             r = need({{a.cp1, false}, {a.To, true}, {a.YT, false}});
@@ -984,15 +1208,26 @@ public:
         mark(da, r);
         double* din = da;
         double* dout = db;
-        for (int k = 2; k <= nsweeps; ++k) {
+        int k = 2;  // delta^1 = rhs/diag is the first sweep from a zero iterate
+        if (u_prev) {
+            // warm start: the first sweep runs from delta^0 = gscale (u_old - u_prev) and records
+            // max|delta^1 - delta^0|
+            Range rk = need({{uo, true}, {u_prev, true}, {rhs, false}, {a.cp1, VAR != VAR_T},
+                             {VAR != VAR_T ? a.To : nullptr, true}});
+            JacobiFn<VAR, REACT, JAC_FIRST> fj{g, model, a, rhs, nullptr, dout, p.dt, u_prev, p.gscale};
+            be.nodes_max(fam_jac, fj, rk.lo, rk.hi, ncols, d_red + 8 + 2 * slot_id);
+            mark(dout, rk);
+            std::swap(din, dout);
+        }
+        for (; k <= nsweeps; ++k) {
             Range rk = need({{din, true}, {rhs, false}, {a.cp1, VAR != VAR_T}, {VAR != VAR_T ? a.To : nullptr, true}});
             if (k < nsweeps) {
-                JacobiFn<VAR, REACT, false> fj{g, model, a, rhs, din, dout, p.dt};
+                JacobiFn<VAR, REACT, JAC_PLAIN> fj{g, model, a, rhs, din, dout, p.dt};
                 be.nodes(fam_jac, fj, rk.lo, rk.hi, ncols);
                 mark(dout, rk);
                 std::swap(din, dout);
             } else {
-                JacobiFn<VAR, REACT, true> fj{g, model, a, rhs, din, unew, p.dt};
+                JacobiFn<VAR, REACT, JAC_FINAL> fj{g, model, a, rhs, din, unew, p.dt};
                 be.nodes_max(fam_jac, fj, rk.lo, rk.hi, ncols, d_red + 2 * slot_id);
                 mark(unew, rk);
             }
@@ -1006,7 +1241,6 @@ public:
         const double t0 = p.t0, dt = p.dt, t1 = p.t0 + p.dt;
         const ForcingSrc f0 = forcing_src(t0, 0), f1 = forcing_src(t1, 1);
         release_retained();
-        be.step_reset(d_red, 8, REACT == REACT_REG ? p.cs_iters : 0);
 
         // cp-forcing cell averages: reuse the array the last step computed for this time level
         const double* fcp_t0 = nullptr;
@@ -1039,6 +1273,16 @@ public:
             temps.push_back(q);
             return q;
         };
+        // a step that fails half-way (stale ghost rows, out of memory) hands its buffers back
+        struct TempGuard {
+            Ctx* c;
+            std::vector<double*>* t;
+            bool armed = true;
+            ~TempGuard() {
+                if (armed)
+                    for (double* q : *t) c->release(q);
+            }
+        } temp_guard{this, &temps};
         double* cpP = grab();
         double* csP = grab();
         double* ncp = grab();  // t0 parts of the correctors
@@ -1115,9 +1359,12 @@ public:
                 a.YT = YT;
                 a.Ycl = Ycl;
                 a.Ycd = Ycd;
-                newton_solve<VAR_T, CASE, REACT>(p, f1, a, Tn, p.sweeps[0], 0);
-                newton_solve<VAR_CL, CASE, REACT>(p, f1, a, cln, p.sweeps[1], 1);
-                newton_solve<VAR_CD, CASE, REACT>(p, f1, a, cdn, p.sweeps[2], 2);
+                // (the increment of the step before is a starting iterate for the first Newton step only:
+                // later ones correct a state that already moved)
+                const bool first = (pc == 0 && nw == 0);
+                newton_solve<VAR_T, CASE, REACT>(p, f1, a, Tn, p.sweeps[0], 0, first && p.warm[0] ? prev[0] : nullptr);
+                newton_solve<VAR_CL, CASE, REACT>(p, f1, a, cln, p.sweeps[1], 1, first && p.warm[1] ? prev[1] : nullptr);
+                newton_solve<VAR_CD, CASE, REACT>(p, f1, a, cdn, p.sweeps[2], 2, first && p.warm[2] ? prev[2] : nullptr);
                 To = Tn;
                 clo = cln;
                 cdo = cdn;
@@ -1136,7 +1383,8 @@ public:
         }
 
         double* nxt[5] = {cpU, To, clo, cdo, csU};
-        commit_state(nxt);
+        commit_state(nxt, true, dt);
+        temp_guard.armed = false;
         // keep what tedd_get_residuals needs; hand everything else back
         last.have = (cp_last_used != nullptr);
         last.t1 = t1;
@@ -1244,7 +1492,10 @@ public:
             const int sw = op.sweeps > 0 ? std::max(2, op.sweeps)
                                          : auto_sweeps(dt * std::fabs(dcoef[var - 1]) * q_metric, op.jtol, op.jmax);
             StepParams p{t0, dt, 1, 1, 0, 0.0, {sw, sw, sw}};
-            be.memset0(d_red, 8 * sizeof(double));
+            fold_last_record();  // (the record of a step before this call is judged before it is cleared)
+            record_unfolded = record_unjudged = false;
+            chain_start = next_seq;
+            be.memset0(d_red, 16 * sizeof(double));
             bT_ready = false;
             double* unew = pool.get();
             double* res = op.out[1] ? pool.get() : nullptr;
@@ -1342,23 +1593,38 @@ public:
             opt_cache_forcing = value != 0.0;
         else if (name == "fuse_forcing")
             opt_fuse_forcing = value < 0.0 ? -1 : (value != 0.0);
+        else if (name == "warm_start") {
+            opt_warm = value != 0.0;
+            if (!opt_warm) drop_prev();
+        }
         else
             throw InvalidError("unknown option: " + name);
     }
 
     void get_stats(tedd_step_stats* s) {
-        double red[8];
+        double red[20];
         int ints[4];
-        be.d2h(red, d_red, 8 * sizeof(double));
+        fold_last_record();
+        be.d2h(red, d_red, 20 * sizeof(double));
         be.d2h(ints, d_ints, 4 * sizeof(int));
         be.sync();
+        const StepMeta& ml = meta[(next_seq - 1 + kRing) % kRing];
+        const bool have_meta = next_seq > 0 && ml.seq == next_seq - 1;
         for (int v = 0; v < 3; ++v) {
             s->sweeps[v] = last.sweeps[v];
             s->last_update[v] = red[2 * v];
             s->increment[v] = red[2 * v + 1];
+            s->warm_started[v] = (have_meta && record_unfolded && ml.warm[v]) ? 1 : 0;
+            s->first_update[v] = red[8 + 2 * v];
+            s->worst_ratio[v] = red[16 + v];
         }
+        s->reserved = 0;
         s->cs_iterations = last.cs_newton_ran ? ints[0] : 0;
         raise_corrector_flag(ints[1]);
+    }
+    void set_reduce_hook(tedd_reduce_fn fn, void* user) {
+        be.reduce_hook = fn;
+        be.reduce_user = user;
     }
     // The reference raises ValueError inside step() (prob1base.py:3406-3409); the device records the
     // condition and the first call that synchronises reports it.
@@ -1397,6 +1663,9 @@ public:
         if (react == REACT_HCS) be.d2h(&flag, d_ints + 1, sizeof(int));
         be.sync();
         raise_corrector_flag(flag);
+        // every solve of the run is judged: an under-converged Jacobi solve in any step is an error here,
+        // where the reference's direct solve (src/prob1base.py:2103,2130) cannot fail that way
+        if (integrator != 0) check_converged();
     }
 };
 

@@ -157,14 +157,32 @@ __global__ void k_cs_init(unsigned long long* gmax, unsigned long long* gmin, in
         gmin[k] = 0x7FF0000000000000ull;  // +inf
     }
 }
-// start of a predictor-corrector step: the record of the Newton solves (nred doubles) and that of the
-// cs corrector, cleared by one launch
-__global__ void k_step_reset(double* red, int nred, unsigned long long* gmax, unsigned long long* gmin, int iters) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < nred) red[k] = 0.0;
-    if (k < iters) {
-        gmax[k] = 0ull;
-        gmin[k] = 0x7FF0000000000000ull;
+// Start of a predictor-corrector step (one workgroup).  Folds the convergence record of the step before
+// into the sticky worst ratio  last_update / (tol * increment)  per system, publishes that record to a
+// host-visible ring slot (the host reads it two steps later to choose sweep counts, without ever
+// synchronising with the stream), then clears the record of the Newton solves and that of the cs corrector.
+__global__ void k_step_prologue(const StepRecordArgs a, unsigned long long* gmax, unsigned long long* gmin) {
+    const int k = threadIdx.x;
+    __shared__ double rec[16];
+    if (k < 16) rec[k] = a.red[k];
+    __syncthreads();
+    if (k < 3 && a.fold) fold_record(a, rec, k);
+    if (k == 0 && a.ring_slot) {
+        double* slot = a.ring_slot;
+        for (int v = 0; v < 3; ++v) {
+            slot[1 + v] = rec[2 * v];
+            slot[4 + v] = rec[2 * v + 1];
+            slot[7 + v] = rec[8 + 2 * v];
+        }
+        __threadfence_system();
+        *(volatile double*)slot = a.seq;
+    }
+    if (a.clear) {
+        if (k < 16) a.red[k] = 0.0;
+        for (int q = k; q < a.cs_iters; q += blockDim.x) {
+            gmax[q] = 0ull;
+            gmin[q] = 0x7FF0000000000000ull;
+        }
     }
 }
 // number of cs Newton iterations the reference keeps: k+1 for the first k with max|dx_k| < rtol min|x_k|
@@ -319,6 +337,9 @@ struct HipBackend {
     unsigned long long* d_csstats = nullptr;  // [4096] max, [4096] min
     int cs_record_clean = 0;                  // leading entries of both known to hold their initial values
     bool profiling = false;
+    // reduction of the cs corrector's record across the slabs of a decomposed mesh (tedd_set_reduce_hook)
+    tedd_reduce_fn reduce_hook = nullptr;
+    void* reduce_user = nullptr;
     struct Rec {
         int fam;
         hipEvent_t a, b;
@@ -391,15 +412,27 @@ struct HipBackend {
         if (p) (void)hipFree(p);
     }
     void memset0(void* p, size_t bytes) { TEDD_HIP(hipMemsetAsync(p, 0, bytes, stream)); }
-    // clears the record of a step's Newton solves (nred doubles at red) and, for cs_iters > 0, the
-    // record of the cs corrector's Newton iteration
-    void step_reset(double* red, int nred, int cs_iters) {
-        if (cs_iters > 4096) cs_iters = 0;  // (refused later, by correct)
-        const int n = nred > cs_iters ? nred : cs_iters;
-        hipLaunchKernelGGL(k_step_reset, dim3((n + 255) / 256), dim3(256), 0, stream, red, nred, d_csstats,
-                           d_csstats + 4096, cs_iters);
+    // prologue of a step: fold / publish the record of the step before, clear the records (k_step_prologue)
+    void step_prologue(StepRecordArgs a) {
+        if (a.cs_iters > 4096) a.cs_iters = 0;  // (refused later, by correct)
+        hipLaunchKernelGGL(k_step_prologue, dim3(1), dim3(256), 0, stream, a, d_csstats, d_csstats + 4096);
         TEDD_HIP(hipGetLastError());
-        cs_record_clean = cs_iters;
+        if (a.clear) cs_record_clean = a.cs_iters;
+    }
+    // host-visible memory the device writes and the host polls (the ring of step records)
+    void* alloc_host_visible(size_t bytes) {
+        void* p = nullptr;
+        TEDD_HIP(hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(p, 0, bytes);
+        return p;
+    }
+    void free_host_visible(void* p) {
+        if (p) (void)hipHostFree(p);
+    }
+    void* device_view(void* host_visible) {
+        void* d = nullptr;
+        TEDD_HIP(hipHostGetDevicePointer(&d, host_visible, 0));
+        return d;
     }
     void h2d(void* d, const void* s, size_t bytes) {
         TEDD_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream));
@@ -457,6 +490,9 @@ struct HipBackend {
         }
     }
     void sync() { TEDD_HIP(hipStreamSynchronize(stream)); }
+    void sync_quiet() noexcept {
+        if (stream) (void)hipStreamSynchronize(stream);
+    }
     // Several pitched device fields to dense host arrays, synchronously.  Small fields (a state of a
     // convergence-study mesh) go through one pinned buffer: one transfer and one wait instead of one per field.
     double* h_pinned = nullptr;
@@ -627,7 +663,8 @@ struct HipBackend {
     void solve_strip(int fam, StripArgs A, int ncols, int shape = -1) {
         if (A.r1 <= A.r0) return;
         if (A.H < 0 || A.H > 16 || A.nsweeps < 0 || A.nsweeps > A.H) throw std::runtime_error("bad strip-solve depth");
-        if (A.b_in == nullptr || A.d_in == nullptr) throw std::runtime_error("strip solve needs rhs and delta^1");
+        if (A.b_in == nullptr || (A.d_in == nullptr && A.u_prev == nullptr))
+            throw std::runtime_error("strip solve needs rhs/diag and a starting iterate");
         Scope sc(this, fam);
         const int TIC = kSTile - 2 * strip_col_halo(A.H);
         A.tiles_x = (ncols + TIC - 1) / TIC;
@@ -678,6 +715,13 @@ struct HipBackend {
             cs_record_clean = 0;
             hipLaunchKernelGGL(k_cs_newton<CASE>, dim3(nb), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx, nt,
                                cp_out, cs_out, iters, true, rtol, d_keep, gmax, gmin);
+            // the record holds bit patterns of non-negative doubles (+inf where nothing was seen): their
+            // order as doubles is their order as integers, so the hook may reduce them as doubles
+            if (reduce_hook && iters > 0) {
+                TEDD_HIP(hipGetLastError());
+                if (reduce_hook(reduce_user, reinterpret_cast<double*>(gmax), reinterpret_cast<double*>(gmin), iters) != 0)
+                    throw std::runtime_error("the reduce hook failed (cs corrector record)");
+            }
             if (iters > 1)  // decides by itself whether anything is left to do
                 hipLaunchKernelGGL(k_cs_newton<CASE>, dim3(nb), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx,
                                    nt, cp_out, cs_out, iters, false, rtol, d_keep, gmax, gmin);

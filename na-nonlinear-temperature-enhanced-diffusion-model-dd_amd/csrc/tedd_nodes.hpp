@@ -391,13 +391,47 @@ struct StripArgs {
     int nsweeps;     // sweeps performed by this launch (<= H)
     int tiles_x;
     unsigned long long* stats;
+    // warm start (first launch of a chain only): the iteration starts from
+    // delta^0 = gscale * (lagged unknown - u_prev), the increment of the time step before, instead of 0,
+    // and max|delta^1 - delta^0| over the nodes written is recorded in stats_first[0]
+    const double* u_prev = nullptr;
+    double gscale = 0.0;
+    unsigned long long* stats_first = nullptr;
 };
 
+// Convergence record of the Newton solves of one step (device memory, `red`):
+//   red[2v], red[2v+1]   max|delta^S - delta^(S-1)| (last update) and max|delta^S| (increment), v = T, cl, cd
+//   red[8+2v]            max|delta^1 - delta^0| of a warm-started solve (first update)
+//   red[16+v]            sticky: worst last_update / (tol * increment) over the steps folded so far
+// The prologue of the next step folds a record into the sticky ratios (systems with tol[v] > 0 only: sweep
+// counts the caller fixed are the caller's responsibility) and publishes it to the host.
+struct StepRecordArgs {
+    double* red;
+    double* ring_slot;  // host-visible {seq, last_update[3], increment[3], first_update[3]}; may be null
+    double seq;
+    double tol[3];
+    int fold, clear, cs_iters;
+};
+TEDD_HD void fold_record(const StepRecordArgs& a, const double* rec, int v) {
+    if (!(a.tol[v] > 0.0)) return;
+    const double upd = rec[2 * v], inc = rec[2 * v + 1];
+    double ratio = 0.0;
+    if (upd != upd || inc != inc)
+        ratio = INFINITY;
+    else if (upd > 0.0)
+        ratio = (inc > 0.0) ? upd / (a.tol[v] * inc) : INFINITY;
+    const double old = a.red[16 + v];
+    a.red[16 + v] = (ratio > old || old != old) ? ratio : old;
+}
+
 // K_jacobi: one matrix-free Jacobi sweep; coefficients are rebuilt from the lagged fields.
-// FINAL: write the updated unknown u_new = u_old + delta instead of delta (boundary rule:
+// MODE JAC_FINAL: write the updated unknown u_new = u_old + delta instead of delta (boundary rule:
 // T -> 0, cl/cd keep their boundary values, prob1base.py:3038-3039, 2102-2106) and report
 // { max|delta_new - delta_in|, max|delta_new| } for the convergence record.
-template <int VAR, int REACT, bool FINAL>
+// MODE JAC_FIRST: first sweep of a warm-started solve: the incoming iterate is not an array but
+// delta^0 = gscale * (u_old - u_prev), the increment of the time step before; reports max|delta^1 - delta^0|.
+enum : int { JAC_PLAIN = 0, JAC_FINAL = 1, JAC_FIRST = 2 };
+template <int VAR, int REACT, int MODE>
 struct JacobiFn {
     GridDev g;
     ModelC m;
@@ -406,22 +440,31 @@ struct JacobiFn {
     const double* din;
     double* out;
     double dt;
+    const double* u_prev = nullptr;  // JAC_FIRST
+    double gscale = 0.0;
     static constexpr int NR = 2;
+    TEDD_HD double iterate_in(const double* uo, int li, int j) const {
+        const size_t c = at(g, li, j);
+        if (MODE != JAC_FIRST) return din[c];
+        // delta^0 lives on the nodes the system has unknowns at (0 on boundary nodes, like every iterate)
+        return is_interior(g, li, j) ? gscale * (uo[c] - u_prev[c]) : 0.0;
+    }
     TEDD_HD void operator()(int li, int j, double* red) const {
         const size_t c = at(g, li, j);
         const double* uo = (VAR == VAR_T) ? a.To : (VAR == VAR_CL) ? a.clo : a.cdo;
         if (!is_interior(g, li, j)) {
             const int i = g.i0 + li;
             const bool global_bd = (i == 0 || i == g.N || j == 0 || j == g.M);
-            if (FINAL) out[c] = (VAR == VAR_T && global_bd) ? 0.0 : uo[c];
+            if (MODE == JAC_FINAL) out[c] = (VAR == VAR_T && global_bd) ? 0.0 : uo[c];
             else out[c] = 0.0;
             return;
         }
         double diag, oe, ow, on, os;
         newton_row<VAR, REACT>(m, g, a, li, j, dt, diag, oe, ow, on, os);
-        const double dn =
-            tedd_div(rhs[c] + oe * din[c + g.ld] + ow * din[c - g.ld] + on * din[c + 1] + os * din[c - 1], diag);
-        if (FINAL) {
+        const double de = iterate_in(uo, li + 1, j), dw = iterate_in(uo, li - 1, j);
+        const double dnn = iterate_in(uo, li, j + 1), ds = iterate_in(uo, li, j - 1);
+        const double dn = tedd_div(rhs[c] + oe * de + ow * dw + on * dnn + os * ds, diag);
+        if (MODE == JAC_FINAL) {
             out[c] = uo[c] + dn;
             const double up = fabs(dn - din[c]), mag = fabs(dn);
             red[0] = up > red[0] ? up : red[0];
@@ -429,6 +472,11 @@ struct JacobiFn {
             if (up != up || mag != mag) red[0] = INFINITY;
         } else {
             out[c] = dn;
+            if (MODE == JAC_FIRST) {
+                const double up = fabs(dn - iterate_in(uo, li, j));
+                red[0] = (up > red[0] || up != up) ? up : red[0];
+                if (up != up) red[0] = INFINITY;
+            }
         }
     }
     TEDD_HD void operator()(int li, int j) const {

@@ -41,7 +41,13 @@ class TeddStepStats(C.Structure):
     _fields_ = [
         ("sweeps", C.c_int32 * 3), ("cs_iterations", C.c_int32),
         ("last_update", C.c_double * 3), ("increment", C.c_double * 3),
+        ("warm_started", C.c_int32 * 3), ("reserved", C.c_int32),
+        ("first_update", C.c_double * 3), ("worst_ratio", C.c_double * 3),
     ]
+
+
+# int (*tedd_reduce_fn)(void* user, double* dev_max, double* dev_min, int32_t n)
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32)
 
 
 # name -> (restype, argtypes); every symbol include/tedd.h declares
@@ -83,6 +89,8 @@ PROTOTYPES = {
     "tedd_error_norms": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(_dptr), _dptr]),
     "tedd_error_norms_noalloc": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),
     "tedd_get_stats": (C.c_int, [C.c_void_p, C.POINTER(TeddStepStats)]),
+    "tedd_check_converged": (C.c_int, [C.c_void_p]),
+    "tedd_set_reduce_hook": (C.c_int, [C.c_void_p, REDUCE_FN, C.c_void_p]),
     "tedd_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "tedd_profile_get": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), _dptr]),
 }
@@ -186,6 +194,9 @@ class Context:
 
     def _check(self, rc):
         if rc < 0:
+            err, self._hook_error = getattr(self, "_hook_error", None), None
+            if err is not None:
+                raise err
             _raise(rc, (self._lib.tedd_last_error(self._h) or b"").decode())
         return rc
 
@@ -309,7 +320,33 @@ class Context:
         s = TeddStepStats()
         self._check(self._lib.tedd_get_stats(self._h, C.byref(s)))
         return {"sweeps": list(s.sweeps), "cs_iterations": int(s.cs_iterations),
-                "last_update": list(s.last_update), "increment": list(s.increment)}
+                "last_update": list(s.last_update), "increment": list(s.increment),
+                "warm_started": [bool(w) for w in s.warm_started], "first_update": list(s.first_update),
+                "worst_ratio": list(s.worst_ratio)}
+
+    def check_converged(self):
+        """RuntimeError if a Jacobi solve with a library-chosen sweep count missed its tolerance by more than a
+        factor 10 in some step since the last check (tedd_check_converged)."""
+        self._check(self._lib.tedd_check_converged(self._h))
+
+    def set_reduce_hook(self, fn):
+        """fn(dev_max_address, dev_min_address, n) -> None, or None to remove the hook (tedd_set_reduce_hook).
+        An exception raised by fn fails the step and is re-raised by the call that was running."""
+        if fn is None:
+            self._reduce_cb = None
+            self._check(self._lib.tedd_set_reduce_hook(self._h, C.cast(None, REDUCE_FN), None))
+            return
+
+        def trampoline(_user, pmax, pmin, n):
+            try:
+                fn(int(pmax), int(pmin), int(n))
+                return 0
+            except BaseException as e:  # noqa: BLE001 -- must not propagate through the C frames
+                self._hook_error = e
+                return 1
+
+        self._reduce_cb = REDUCE_FN(trampoline)   # keep it alive as long as the library may call it
+        self._check(self._lib.tedd_set_reduce_hook(self._h, self._reduce_cb, None))
 
     # -- parity hooks
     def eval_field(self, t):

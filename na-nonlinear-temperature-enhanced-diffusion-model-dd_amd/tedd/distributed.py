@@ -62,11 +62,16 @@ def partition_rows(n_rows: int, world: int, rank: int, ghost: int) -> Slab:
     return Slab(rank, world, n_rows, lo, hi, ghost if world > 1 else 0)
 
 
+_HAS_FOREACH_COPY = hasattr(torch, "_foreach_copy_")
+
+
 def _copy_many(dsts, srcs):
-    """dst[k] <- src[k] for lists of equally shaped tensors, as one multi-tensor launch where torch has it."""
-    try:
+    """dst[k] <- src[k] for lists of equally shaped tensors, as one multi-tensor launch where this torch has
+    the multi-tensor copy (a capability of the installed build, tested once at import; an error raised by the
+    copy itself is an error of the exchange and is not caught)."""
+    if _HAS_FOREACH_COPY:
         torch._foreach_copy_(dsts, srcs)
-    except (AttributeError, RuntimeError, TypeError):
+    else:
         for d, s in zip(dsts, srcs):
             d.copy_(s)
 
@@ -181,17 +186,53 @@ def wrap_device_fields(ptrs, rows, pitch, device):
     return [torch.as_tensor(_DeviceArray(p, rows, pitch), device=device) for p in ptrs]
 
 
+def _wrap_vector(ptr, n, device):
+    """torch view (n, float64) of device memory (host memory on a CPU device)."""
+    if device.type == "cpu":
+        import ctypes
+
+        import numpy as np
+        buf = (ctypes.c_double * n).from_address(int(ptr))
+        return torch.from_numpy(np.frombuffer(buf, dtype=np.float64))
+
+    holder = _DeviceArray(ptr, 1, n)
+    holder.__cuda_array_interface__["shape"] = (n,)
+    return torch.as_tensor(holder, device=device)
+
+
 class SlabStepper:
-    """Drives one context per rank: step on the slab, exchange ghost rows, repeat."""
+    """Drives one context per rank: step on the slab, exchange ghost rows, repeat.
+
+    Decisions the reference takes from quantities over the whole mesh are taken over all slabs:
+    the early exit of the cs corrector's Newton iteration (reference src/prob1base.py:3661) through the
+    context's reduce hook (an all-reduce of the per-iteration record between the two passes of that
+    corrector), the HCsTriple corrector's ValueError and the verdict on the Jacobi solves through
+    `check_converged`, which every rank must call at the same points."""
 
     def __init__(self, ctx, slab: Slab, device, group=None):
         self.ctx = ctx
         self.slab = slab
         self.device = device
+        self.group = group
         self.halo = HaloExchange(slab, group)
         self._wrapped = {}
         if device.type == "cuda":
             ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        if slab.world > 1:
+            ctx.set_reduce_hook(self._reduce_record)
+
+    def _reduce_record(self, pmax, pmin, n):
+        tmax = _wrap_vector(pmax, n, self.device)
+        tmin = _wrap_vector(pmin, n, self.device)
+        if tmax.is_cuda and dist.get_backend(self.group) == "gloo":   # no device collectives: through the host
+            hmax, hmin = tmax.cpu(), tmin.cpu()
+            dist.all_reduce(hmax, op=dist.ReduceOp.MAX, group=self.group)
+            dist.all_reduce(hmin, op=dist.ReduceOp.MIN, group=self.group)
+            tmax.copy_(hmax)
+            tmin.copy_(hmin)
+        else:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=self.group)
+            dist.all_reduce(tmin, op=dist.ReduceOp.MIN, group=self.group)
 
     def _fields(self):
         # the state arrays rotate through a small pool of device buffers: wrap each address once
@@ -221,6 +262,28 @@ class SlabStepper:
     def step_feuler(self, t0, dt):
         self.ctx.step_feuler(t0, dt)
         self.refresh_ghosts()
+
+    def check_converged(self):
+        """Collective: raises on EVERY rank if the Jacobi solves of some step missed their tolerance on any slab
+        (RuntimeError), or the HCsTriple corrector met a non-positive denominator on any slab (ValueError)."""
+        err = None
+        try:
+            self.ctx.get_stats()         # raises the corrector's ValueError of this slab
+            self.ctx.check_converged()   # raises RuntimeError for this slab's solves
+        except (ValueError, RuntimeError) as e:
+            err = e
+        if self.slab.world > 1:
+            code = 0 if err is None else (1 if isinstance(err, ValueError) else 2)
+            flag = torch.tensor([code], dtype=torch.int32)
+            if dist.get_backend(self.group) != "gloo":
+                flag = flag.to(self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            worst = int(flag.item())
+            if err is None and worst:
+                err = (ValueError if worst == 1 else RuntimeError)("another slab reported: " + (
+                    "HCsTriple corrector denominator not positive" if worst == 1 else "a Jacobi solve missed its tolerance"))
+        if err is not None:
+            raise err
 
 
 # ------------------------------------------------------------------------------------------

@@ -31,7 +31,10 @@ def test_sweep_counts_follow_the_contraction_bound():
         assert bench.pick_sweeps(N, (1.0 / N) ** 1.5, 1e-13) == expect
 
 
-def test_committed_pmc_summary_feeds_the_traffic_figure():
+def test_committed_pmc_summary_feeds_the_traffic_figure(monkeypatch):
+    # (the mechanism, on the counter summary of the first round's kernels; bench.py itself only accepts
+    # summaries of the kernels of the present tree, PMC_PROFILE_TAG)
+    monkeypatch.setattr(bench, "PMC_PROFILE_TAG", "r01_v9")
     cfg = {"mesh_N": 16384, "solver": "strip", "sweeps_per_launch": 10, "forcing": "arrays per time level"}
     tr = bench.pmc_traffic("predict", cfg)
     assert tr is not None and tr["source"].startswith("profiles/")
@@ -62,3 +65,34 @@ def test_bench_prints_one_line_with_the_agreed_fields():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     assert np.isfinite(d["config"]["error_H_after_run"])
+
+
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_launches_its_own_ranks(scaling):
+    """`python bench.py --gpus 2` outside torch.distributed.run: the process starts the two ranks itself (gloo
+    on the host twin here, RCCL on GPUs), passes rank 0's line through and returns the launcher's status."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_twin_cabi_parity import TWIN, build_twin
+    build_twin()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mesh", "64", "--steps", "2",
+                          "--warmup", "1", "--library", TWIN, "--backend", "gloo", "--device", "cpu", "--scaling", scaling],
+                         capture_output=True, text=True, timeout=280, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo" and d["scaling"] == scaling
+    assert d["steps"] == 2 and d["warmup"] == 1
+    units = 2 * (2 if scaling == "weak" else 1)
+    assert d["value"] == pytest.approx(units * 1e3 / (2 * d["ms_per_step"]), rel=1e-9)
+    assert ("[0,2]x[0,1]" in d["config"]["workload"]) == (scaling == "weak")
+    assert d["config"]["error_H_after_run"] < 1e-3
+
+
+def test_bench_fails_when_a_rank_fails():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mesh", "64", "--steps", "1",
+                          "--warmup", "0", "--library", "/nonexistent/libtedd.so", "--backend", "gloo", "--device", "cpu"],
+                         capture_output=True, text=True, timeout=280, cwd=ROOT, env=env)
+    assert out.returncode != 0

@@ -46,7 +46,7 @@ def test_partition_covers_all_rows():
         partition_rows(9, 2, 0, 0)
 
 
-def _worker(rank, world, port, case, N, M, nsteps, kind, consts, sweeps, ghost, out_dir, options):
+def _worker(rank, world, port, case, N, M, nsteps, kind, consts, sweeps, ghost, out_dir, options, step_kw=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -67,23 +67,25 @@ def _worker(rank, world, port, case, N, M, nsteps, kind, consts, sweeps, ghost, 
         norms = []
         for _ in range(nsteps):
             if kind == "pc":
-                stepper.step_pc(t, dt, jacobi_sweeps=sweeps)
+                stepper.step_pc(t, dt, jacobi_sweeps=sweeps, **(step_kw or {}))
             else:
                 stepper.step_feuler(t, dt)
             t += dt
             local = torch.from_numpy(ctx.error_norms(t))
             dist.all_reduce(local)
             norms.append(local.numpy().copy())
+        stepper.check_converged()
         state = ctx.get_state()
         a, b = slab.owned_local
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=slab.row_lo, hi=slab.row_hi,
-                 norms=np.array(norms), **{f"f{k}": s[a:b] for k, s in enumerate(state)})
+                 norms=np.array(norms), cs_iterations=ctx.get_stats()["cs_iterations"],
+                 **{f"f{k}": s[a:b] for k, s in enumerate(state)})
         ctx.close()
     finally:
         dist.destroy_process_group()
 
 
-def _single(case, N, M, nsteps, kind, consts, sweeps):
+def _single(case, N, M, nsteps, kind, consts, sweeps, step_kw=None):
     from test_twin_cabi_parity import TWIN, build_twin
     from tedd import _ffi
     build_twin()
@@ -96,12 +98,13 @@ def _single(case, N, M, nsteps, kind, consts, sweeps):
     norms = []
     for _ in range(nsteps):
         if kind == "pc":
-            ctx.step_pc(t, dt, jacobi_sweeps=sweeps)
+            ctx.step_pc(t, dt, jacobi_sweeps=sweeps, **(step_kw or {}))
         else:
             ctx.step_feuler(t, dt)
         t += dt
         norms.append(ctx.error_norms(t))
     out = ctx.get_state()
+    _single.cs_iterations = ctx.get_stats()["cs_iterations"]
     ctx.close()
     return out, np.array(norms)
 
@@ -131,6 +134,95 @@ def test_slab_run_equals_single_domain(world, kind, case, consts, options, tmp_p
         np.testing.assert_allclose(z["norms"], ref_norms, rtol=1e-12, atol=1e-300)
         rows += hi - lo
     assert rows == N + 1
+
+
+def _positive_state(N, M):
+    """A smooth state whose cs is positive on every node, boundary included (min |x| of the cs Newton iteration
+    is then not the rounding noise of a zero boundary value) and grows along x, so that slabs see different
+    minima."""
+    i = np.arange(N + 1)[:, None] / N
+    j = np.arange(M + 1)[None, :] / M
+    cp = 0.3 + 0.2 * np.sin(2 * i + j)
+    T = 0.5 + 0.1 * np.cos(i - 3 * j)
+    cl = 0.2 * np.sin(3 * i * j)
+    cd = 0.4 + 0.1 * i * j
+    cs = 0.02 + 0.9 * i ** 2 + 0.05 * j
+    return [np.ascontiguousarray(a) for a in (cp, T, cl, cd, cs)]
+
+
+def _early_exit_run(ctx, stepper, rows, N, M, nsteps, kw):
+    zero = np.zeros((ctx.nrows, M + 1))
+    lo = ctx.row_offset
+    ctx.set_state(*[a[lo:lo + ctx.nrows] for a in _positive_state(N, M)])
+    kept = []
+    for k in range(nsteps):
+        ctx.set_forcing(0, zero, zero, zero, zero, zero)
+        ctx.set_forcing(1, zero, zero, zero, zero, zero)
+        if stepper is None:
+            ctx.step_pc(0.05 * k, 0.05, **kw)
+        else:
+            stepper.step_pc(0.05 * k, 0.05, **kw)
+        kept.append(ctx.get_stats()["cs_iterations"])
+    return kept
+
+
+def _early_exit_worker(rank, world, port, N, M, nsteps, kw, ghost, use_hook, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_twin_cabi_parity import TWIN
+        from tedd import _ffi
+        _ffi.use_library(TWIN)
+        x = np.linspace(0, 1, N + 1)
+        y = np.linspace(0, 1, M + 1)
+        slab = partition_rows(N + 1, world, rank, ghost)
+        ctx = _ffi.Context(x, y, STRESS, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0, mms_case=-1,
+                           row_lo=slab.row_lo, row_hi=slab.row_hi, ghost=slab.ghost)
+        stepper = SlabStepper(ctx, slab, torch.device("cpu"))
+        if not use_hook:
+            ctx.set_reduce_hook(None)
+        kept = _early_exit_run(ctx, stepper, slab, N, M, nsteps, kw)
+        a, b = slab.owned_local
+        np.savez(os.path.join(out_dir, f"exit{rank}.npz"), lo=slab.row_lo, hi=slab.row_hi, kept=np.array(kept),
+                 **{f"f{k}": s[a:b] for k, s in enumerate(ctx.get_state())})
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cs_corrector_early_exit_is_decided_over_all_slabs(world, tmp_path):
+    """The reference stops the cs corrector's Newton iteration when max|dx| < rtol min|x| over ALL nodes
+    (src/prob1base.py:3661).  On a state whose cs is positive everywhere the exit fires; every slab must then
+    keep the iteration count the whole mesh decides (all-reduce of the per-iteration record between the two
+    passes of the corrector) and reproduce the single-domain state bit for bit.  Without the all-reduce the
+    slabs decide differently -- the last assertion shows that the case can tell."""
+    from test_twin_cabi_parity import TWIN, build_twin
+    from tedd import _ffi
+    build_twin()
+    _ffi.use_library(TWIN)
+    N, M, nsteps = 47, 21, 3
+    kw = dict(cs_newton_iterations=12, cs_consec_xs_rtol=2e-3, jacobi_sweeps=[4, 3, 2])
+    x = np.linspace(0, 1, N + 1)
+    ctx = _ffi.Context(x, np.linspace(0, 1, M + 1), STRESS, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE,
+                       eta=50.0, mms_case=-1)
+    kept_ref = _early_exit_run(ctx, None, None, N, M, nsteps, kw)
+    ref_state = ctx.get_state()
+    ctx.close()
+    assert all(1 <= k < 12 for k in kept_ref), kept_ref        # the early exit fired on the whole mesh
+    seen = {}
+    for use_hook in (True, False):
+        out = tmp_path / f"hook{int(use_hook)}"
+        out.mkdir()
+        port = 29500 + (os.getpid() % 2000) + 20 + world + 4 * int(use_hook)
+        mp.spawn(_early_exit_worker, args=(world, port, N, M, nsteps, kw, 11, use_hook, str(out)), nprocs=world, join=True)
+        seen[use_hook] = [np.load(out / f"exit{r}.npz") for r in range(world)]
+    for z in seen[True]:
+        assert list(z["kept"]) == kept_ref
+        lo, hi = int(z["lo"]), int(z["hi"])
+        for k in range(5):
+            np.testing.assert_array_equal(z[f"f{k}"], ref_state[k][lo:hi])
+    assert any(list(z["kept"]) != kept_ref for z in seen[False])
 
 
 def test_too_few_ghost_rows_is_an_error(tmp_path):

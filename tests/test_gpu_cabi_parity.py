@@ -84,6 +84,20 @@ def test_prefetch_forcing_changes_nothing():
     cc.check_prefetch_forcing()
 
 
+# ---- the verdict on the Jacobi solves and their warm start (reference: direct solves, src/prob1base.py:2088-2130)
+def test_too_few_sweeps_through_advance_is_an_error():
+    cc.check_under_converged_advance_raises()
+
+
+@pytest.mark.parametrize("solver", ["strip", "strip_small_h3", "strip_mid", "sweeps"])
+def test_warm_start_needs_fewer_sweeps_for_the_same_tolerance(solver):
+    cc.check_warm_start_same_answer_fewer_sweeps(SOLVERS[solver])
+
+
+def test_fixed_sweeps_are_not_judged_and_not_warm_started():
+    cc.check_fixed_sweeps_are_plain_jacobi()
+
+
 # ---- exact solutions given as expression programs (TEDD_MMS_PROGRAM)
 @pytest.mark.parametrize("react", ["reg", "cs3", "hcs"])
 def test_mms_program_equals_closed_form(react):

@@ -22,7 +22,7 @@ def build_twin():
     srcs.append(os.path.join(ROOT, "include", "tedd.h"))
     if os.path.exists(TWIN) and all(os.path.getmtime(TWIN) >= os.path.getmtime(s) for s in srcs):
         return
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC, "-o", TWIN,
+    subprocess.check_call(["g++", "-O2", "-fopenmp", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC, "-o", TWIN,
                            os.path.join(TWIN_DIR, "tedd_twin.cpp")])
 
 
