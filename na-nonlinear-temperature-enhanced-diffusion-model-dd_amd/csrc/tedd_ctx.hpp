@@ -83,10 +83,11 @@ public:
                                   // worst ratios (see StepRecordArgs), [32..39] error norms
     // History of the convergence records.  Every predictor-corrector step has a sequence number that is
     // never reused; the prologue launch of step g+1 publishes the record of step g to ring slot g % kRing
-    // (host-visible memory), and step g+2 reads it there to choose its sweep counts -- by then the
-    // prologue of step g+1 has run unless the host is more than a step ahead of the GPU, in which case
-    // it waits for that one small launch, never for a step.
+    // (host-visible memory), and step g+kLag reads it there to choose its sweep counts -- by then the
+    // prologue of step g+1 has run unless the host is more than kLag-1 steps ahead of the GPU, in which
+    // case it waits for that one small launch, never for a step.
     static constexpr int kRing = 8;
+    static constexpr int kLag = 4;
     double* h_ring = nullptr;     // kRing x 16 doubles, host-visible
     double* d_ring = nullptr;     // the same memory as the device addresses it
     struct StepMeta {
@@ -105,6 +106,10 @@ public:
     double* prev[3] = {nullptr, nullptr, nullptr};
     double prev_dt = 0.0;
     int opt_warm = 1;             // start the Jacobi iteration from the increment of the step before
+    // a warm start reads two more arrays than a start from zero: where the record says it would not save
+    // three sweeps or a launch, that system starts from zero until this sequence number (then it is tried again)
+    long long cold_until[3] = {0, 0, 0};
+    static constexpr int kColdSpell = 64;
     double* d_series = nullptr;   // error-norm series of tedd_advance
     size_t series_cap = 0;
     int* d_ints = nullptr;        // [0] cs iterations kept, [1] HCsTriple corrector: denominator not positive
@@ -536,6 +541,7 @@ public:
         release_retained();
         drop_prev();
         chain_start = next_seq;  // records of steps before this point say nothing about the new state
+        for (int v = 0; v < 3; ++v) cold_until[v] = 0;
     }
     void ensure_state_buffers() {
         for (int v = 0; v < 5; ++v)
@@ -876,9 +882,11 @@ public:
     // per Jacobi sweep; from a zero iterate ceil(log tol / log rho) + 1 sweeps bring the last update below
     // tol x increment.  With the state of the step before at hand the iteration starts from that step's
     // increment instead (the increments of consecutive steps differ by O(dt)), and the count follows from
-    // the first update max|delta^1 - delta^0| / max|delta| that the step two before this one recorded for
+    // the first update max|delta^1 - delta^0| / max|delta| that the step kLag before this one recorded for
     // its own warm start (with a factor 4 of margin), never more than the cold count plus one.  The record
-    // also carries the contraction actually seen, which replaces the bound where it is worse.
+    // also carries the contraction actually seen, which replaces the bound where it is worse.  A warm start
+    // reads two more arrays (the lagged unknown and the one before): it is used where it saves at least
+    // three sweeps or a launch of the chain; otherwise the system goes back to zero iterates for a while.
     void choose_sweeps(StepParams& p, const int32_t* sweeps_in, double jtol, int jmax, StepMeta& mt) {
         const double dcoef[3] = {model.DT, model.Dl_max, model.Dd_max};
         const bool partial = (gl > 0 || gr > 0);
@@ -903,24 +911,24 @@ public:
             int s = cold;
             bool warm = false;
             mt.tol[v] = jtol;
-            if (can_warm && prev[v]) {
+            if (can_warm && prev[v] && next_seq >= cold_until[v]) {
                 warm = true;
                 s = std::min(cold + (partial ? 0 : 1), jmax);  // until a record says how good the start is
                 if (!asked) {
-                    have_rec = lagged_record(next_seq - 2, upd, inc, first);
+                    have_rec = lagged_record(next_seq - kLag, upd, inc, first);
                     asked = true;
                 }
-                const StepMeta& m2 = meta[(next_seq - 2 + 2 * kRing) % kRing];
-                if (have_rec && m2.seq == next_seq - 2 && m2.warm[v] && inc[v] > 0.0 && first[v] == first[v] &&
+                const StepMeta& m2 = meta[(next_seq - kLag + 2 * kRing) % kRing];
+                if (have_rec && m2.seq == next_seq - kLag && m2.warm[v] && inc[v] > 0.0 && first[v] == first[v] &&
                     upd[v] == upd[v]) {
-                    // contraction seen two steps ago, where the record can tell: a last update within a
-                    // factor 100 of the rounding of the iterate (2^-53 x increment) is noise, not convergence
+                    // contraction seen then, where the record can tell: a last update within a factor 100
+                    // of the rounding of the iterate (2^-53 x increment) is noise, not convergence
                     if (m2.sweeps[v] >= 3 && first[v] > 0.0 && upd[v] > 1e-14 * inc[v]) {
                         const double seen = std::pow(upd[v] / first[v], 1.0 / (m2.sweeps[v] - 1));
                         if (seen > rho && seen < 1.0) rho = seen;
                     }
                     // sweeps after the first so that the last update is below tol / 4 (the start of this
-                    // step is judged by that of the step two before: the factor covers the difference)
+                    // step is judged by that of an earlier one: the factor covers the difference)
                     const double r0 = 4.0 * first[v] / inc[v];
                     if (r0 <= jtol || rho <= 0.0) {
                         s = 2;
@@ -929,6 +937,14 @@ public:
                         if (want < (double)s) s = (int)want;
                     }
                     if (s < 2) s = 2;
+                    // worth the two extra arrays?
+                    const int hmax = std::min(opt_strip_hmax > 0 ? opt_strip_hmax : 10, 16);
+                    auto launches = [&](int sweeps_in_chain) { return std::max(1, (sweeps_in_chain + hmax - 1) / hmax); };
+                    if (!((cold - 1) - s >= 3 || launches(s) < launches(cold - 1))) {
+                        cold_until[v] = next_seq + kColdSpell;
+                        warm = false;
+                        s = cold;
+                    }
                 }
             }
             p.sweeps[v] = s;

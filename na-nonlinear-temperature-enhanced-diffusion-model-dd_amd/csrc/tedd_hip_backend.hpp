@@ -683,15 +683,26 @@ struct HipBackend {
         if ((shape == SHAPE_SMALL && !small_fits) || (shape == SHAPE_MID && !mid_fits)) shape = SHAPE_LARGE;
         const long long nt = n_tiles(shape);
         if (nt > 0x7fffffffLL) throw std::runtime_error("mesh too large for the tile index");
+        const bool warm = (A.u_prev != nullptr);
+        if (warm && A.stats_first == nullptr) throw std::runtime_error("warm strip solve needs a record slot");
+        auto launch = [&](auto shape_c, auto warm_c) {
+            constexpr int SH = decltype(shape_c)::value;
+            constexpr bool WM = decltype(warm_c)::value;
+            hipLaunchKernelGGL((k_solve_strip<VAR, REACT, LAST, SH, WM>), dim3((unsigned)nt),
+                               dim3(kSTile, StripShape<VAR, SH>::W), 0, stream, A);
+        };
+        auto by_warm = [&](auto shape_c) {
+            if (warm)
+                launch(shape_c, std::true_type{});
+            else
+                launch(shape_c, std::false_type{});
+        };
         if (shape == SHAPE_SMALL)
-            hipLaunchKernelGGL((k_solve_strip<VAR, REACT, LAST, SHAPE_SMALL>), dim3((unsigned)nt),
-                               dim3(kSTile, StripShape<VAR, SHAPE_SMALL>::W), 0, stream, A);
+            by_warm(std::integral_constant<int, SHAPE_SMALL>{});
         else if (shape == SHAPE_MID)
-            hipLaunchKernelGGL((k_solve_strip<VAR, REACT, LAST, SHAPE_MID>), dim3((unsigned)nt),
-                               dim3(kSTile, StripShape<VAR, SHAPE_MID>::W), 0, stream, A);
+            by_warm(std::integral_constant<int, SHAPE_MID>{});
         else
-            hipLaunchKernelGGL((k_solve_strip<VAR, REACT, LAST, SHAPE_LARGE>), dim3((unsigned)nt),
-                               dim3(kSTile, StripShape<VAR, SHAPE_LARGE>::W), 0, stream, A);
+            by_warm(std::integral_constant<int, SHAPE_LARGE>{});
         TEDD_HIP(hipGetLastError());
     }
     template <int CASE, int REACT>

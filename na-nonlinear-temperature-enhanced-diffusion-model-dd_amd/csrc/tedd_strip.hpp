@@ -87,7 +87,9 @@ __device__ __forceinline__ double lane_above(double v) {
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-template <int VAR, int REACT, bool LAST, int SHAPE>
+// WARM: first launch of a warm-started chain (StripArgs::u_prev, gscale, stats_first); a separate
+// instantiation so that the launches from zero iterates carry none of its registers and branches.
+template <int VAR, int REACT, bool LAST, int SHAPE, bool WARM = false>
 __global__ void __launch_bounds__((64 * StripShape<VAR, SHAPE>::W)) __attribute__((amdgpu_waves_per_eu((StripShape<VAR, SHAPE>::OCC))))
 k_solve_strip(const StripArgs A) {
     constexpr int R = StripShape<VAR, SHAPE>::R, W = StripShape<VAR, SHAPE>::W, TR = StripShape<VAR, SHAPE>::TR;
@@ -123,12 +125,7 @@ k_solve_strip(const StripArgs A) {
     for (int k = 0; k < R; ++k) {
         const size_t c = (size_t)min(max(row0 + k, 0), rmax) * g.ld + jc;
         b[k] = A.b_in[c];
-        if (LEAN) {
-            if (A.u_prev)  // warm start: the increment of the time step before
-                d[k] = A.gscale * (A.a.To[c] - A.u_prev[c]);
-            else
-                d[k] = A.d_in[c];  // (the same line as b[k] in the first launch of a cold chain)
-        }
+        if (LEAN && !WARM) d[k] = A.d_in[c];  // (the same line as b[k] in the first launch of a cold chain)
         if (VAR == VAR_CD) {
             clv[k] = A.a.clo[c];
             csv[k] = A.a.cs1[c];
@@ -226,13 +223,12 @@ k_solve_strip(const StripArgs A) {
             cs[k] = active ? (A.dt * r.s) * iv : 0.0;
         }
         b[k] = active ? b[k] : 0.0;
-        if (LEAN) d[k] = active ? d[k] : 0.0;
+        if (LEAN && !WARM) d[k] = active ? d[k] : 0.0;
     }
     // full rows: the iterate is loaded last, until here the registers hold the inputs of the rows.
     // (The empty asm ties the load addresses to the end of the set-up so that the loads are not hoisted.)
-    if (LEAN) {
-    } else if (A.u_prev) {  // warm start: the increment of the time step before
-        const double* uo_ = (VAR == VAR_CL) ? A.a.clo : A.a.cdo;
+    if (WARM) {  // warm start: the increment of the time step before
+        const double* uo_ = (VAR == VAR_T) ? A.a.To : (VAR == VAR_CL) ? A.a.clo : A.a.cdo;
         int jd = jc;
         asm volatile("" : "+v"(jd) : "v"(b[R - 1]));
 #pragma unroll
@@ -241,6 +237,7 @@ k_solve_strip(const StripArgs A) {
             const double v = A.gscale * (uo_[c] - A.u_prev[c]);
             d[k] = is_active(row0 + k) ? v : 0.0;
         }
+    } else if (LEAN) {
     } else if (A.d_in == A.b_in) {
 #pragma unroll
         for (int k = 0; k < R; ++k) d[k] = b[k];
@@ -256,8 +253,7 @@ k_solve_strip(const StripArgs A) {
 
     // which of this thread's nodes are written back
     const bool lane_in = (lane >= HC && lane < kSTile - HC && j >= 0 && j < g.ncols);
-    double up_max = 0.0, mag_max = 0.0, first_max = 0.0;
-    const bool want_first = (A.stats_first != nullptr);
+    double up_max = 0.0, mag_max = 0.0;
 
     // ---- sweeps.  The last launch of a chain keeps its final sweep for the write-back below.
     int par = 0;
@@ -289,22 +285,50 @@ k_solve_strip(const StripArgs A) {
     // (lean rows have the registers to fuse the final sweep with the store; full rows do it in place)
     constexpr bool FUSE_FINAL = LAST && LEAN;
     const int in_place = FUSE_FINAL ? max(A.nsweeps - 1, 0) : A.nsweeps;
-    for (int sw = 1; sw <= in_place; ++sw) {
+    int sw0 = 1;
+    if (WARM && in_place >= 1) {
+        // first sweep of a warm chain (a warm chain performs at least two): records max|delta^1 - delta^0|
+        // over the rows and columns this launch writes back (nodes without an unknown contribute 0), reduced
+        // per wave right away so that nothing of it stays live across the other sweeps
         exchange_seams();
-        const bool track = LAST && !FUSE_FINAL && sw == A.nsweeps;
-        const bool track_first = want_first && sw == 1;
+        double first_max = 0.0;
         double prev = above;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const double cur = d[k];
             const double v = update(k, prev, cur, (k < R - 1) ? d[k + 1] : below);
             d[k] = v;
-            if (track || track_first) {
+            const int r = R * wave + k;
+            const double up = (lane_in && r >= H && r < TR - H) ? fabs(v - cur) : 0.0;
+            first_max = (up > first_max || up != up) ? up : first_max;
+            prev = cur;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o = __shfl_xor(first_max, off, 64);
+            first_max = (o > first_max || o != o) ? o : first_max;
+        }
+        if (lane == 0) {
+            if (first_max != first_max) first_max = INFINITY;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(first_max);
+            if (bits > __atomic_load_n(A.stats_first, __ATOMIC_RELAXED)) atomicMax(A.stats_first, bits);
+        }
+        sw0 = 2;
+    }
+    for (int sw = sw0; sw <= in_place; ++sw) {
+        exchange_seams();
+        const bool track = LAST && !FUSE_FINAL && sw == A.nsweeps;
+        double prev = above;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double cur = d[k];
+            const double v = update(k, prev, cur, (k < R - 1) ? d[k + 1] : below);
+            d[k] = v;
+            if (track) {
                 const int r = R * wave + k, li = row0 + k;
                 const bool counted = lane_in && r >= H && r < TR - H && li >= A.r0 && li < A.r1 && is_interior(g, li, j);
                 const double up = counted ? fabs(v - cur) : 0.0;
-                if (track) up_max = (up > up_max || up != up) ? up : up_max;
-                if (track_first) first_max = (up > first_max || up != up) ? up : first_max;
+                up_max = (up > up_max || up != up) ? up : up_max;
             }
             prev = cur;
         }
@@ -365,36 +389,30 @@ k_solve_strip(const StripArgs A) {
             if (r >= H && r < TR - H && li >= A.r0 && li < A.r1 && lane_in) A.d_out[at(g, li, jw)] = d[k];
         }
     }
-    if (LAST || want_first) {
-        // (want_first is launch-uniform; a fused final sweep that is also the first one of a warm chain
-        // cannot happen: a warm chain performs at least two sweeps)
+    if (LAST) {
         __syncthreads();  // the seam rows are dead: reuse their first doubles
         double* red = &seam[0][0][0][0];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             const double o1 = __shfl_xor(up_max, off, 64), o2 = __shfl_xor(mag_max, off, 64);
-            const double o3 = __shfl_xor(first_max, off, 64);
             up_max = (o1 > up_max || o1 != o1) ? o1 : up_max;
             mag_max = (o2 > mag_max || o2 != o2) ? o2 : mag_max;
-            first_max = (o3 > first_max || o3 != o3) ? o3 : first_max;
         }
         if (lane == 0) {
-            red[3 * wave] = up_max;
-            red[3 * wave + 1] = mag_max;
-            red[3 * wave + 2] = first_max;
+            red[2 * wave] = up_max;
+            red[2 * wave + 1] = mag_max;
         }
         __syncthreads();
-        if (wave == 0 && lane < 3) {
+        if (wave == 0 && lane < 2) {
             double v = red[lane];
             for (int w2 = 1; w2 < W; ++w2) {
-                const double o = red[3 * w2 + lane];
+                const double o = red[2 * w2 + lane];
                 v = (o > v || o != o) ? o : v;
             }
             if (v != v) v = INFINITY;
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-            unsigned long long* dst = (lane < 2) ? (LAST ? A.stats + lane : nullptr) : A.stats_first;
             // most tiles do not raise the maximum: skip their atomics
-            if (dst && bits > __atomic_load_n(dst, __ATOMIC_RELAXED)) atomicMax(dst, bits);
+            if (bits > __atomic_load_n(A.stats + lane, __ATOMIC_RELAXED)) atomicMax(A.stats + lane, bits);
         }
     }
 }
