@@ -104,7 +104,11 @@ int tedd_set_mms_program(tedd_ctx* ctx, int32_t which, const uint32_t* code, int
  * forcing once per time level into arrays instead of inside the step kernels; "fuse_forcing" (default -1:
  * slabs of at most 4 M nodes): those arrays are made by the predictor launch instead of a launch of their own;
  * "warm_start" (default 1): a Newton solve whose sweep count the library chooses starts its Jacobi iteration
- * from the increment of the step before instead of zero (same tolerance, fewer sweeps). */
+ * from the increment of the step before instead of zero (same tolerance, fewer sweeps); "march" (default -1:
+ * slabs of at least 2^25 nodes; 0 never, 1 always): the predictor and the right-hand sides of the cl and cd
+ * systems run in the marching launcher (a wavefront walks down 64 columns with the stencil rows in registers:
+ * every array row is read once) instead of one thread per node -- bit-identical results; "march_rows",
+ * "march_occ": rows per segment and waves per SIMD of that launcher (0: the kernel's own choice). */
 int tedd_set_option(tedd_ctx* ctx, const char* name, double value);
 /* Use the caller's HIP stream (hipStream_t passed as void*) for all subsequent work. */
 int tedd_set_stream(tedd_ctx* ctx, void* hip_stream);

@@ -1609,7 +1609,16 @@ public:
             opt_cache_forcing = value != 0.0;
         else if (name == "fuse_forcing")
             opt_fuse_forcing = value < 0.0 ? -1 : (value != 0.0);
-        else if (name == "warm_start") {
+        else if (name == "march" || name == "march_rows" || name == "march_occ") {
+            if constexpr (Backend::kHasStripSolve) {
+                if (name == "march")
+                    be.opt_march = value < 0.0 ? -1 : (value != 0.0);
+                else if (name == "march_rows")
+                    be.opt_march_rows = (int)value;
+                else
+                    be.opt_march_occ = (int)value;
+            }
+        } else if (name == "warm_start") {
             opt_warm = value != 0.0;
             if (!opt_warm) drop_prev();
         }

@@ -10,9 +10,11 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "tedd_strip.hpp"
+#include "tedd_march.hpp"
 #include "tedd_ctx.hpp"
 
 namespace tedd {
@@ -326,8 +328,19 @@ struct CorrectClosedFn {
     }
 };
 
+// node functors that provide the marching interface (tedd_march.hpp)
+template <class F, class = void>
+struct Marches : std::false_type {};
+template <class F>
+struct Marches<F, std::enable_if_t<F::kMarches>> : std::true_type {};
+
 struct HipBackend {
     static constexpr bool kHasStripSolve = true;
+    // marching launcher for the stencil functors: -1 on slabs of at least 2^25 nodes (below, the plain
+    // launcher's many small workgroups fill the GPU better), 0 never, 1 always
+    int opt_march = -1;
+    int opt_march_rows = 0;  // rows per segment (0: per functor, fewer on slabs with few rows)
+    int opt_march_occ = 0;   // waves per SIMD the marching kernels' register budget is set for (0: per functor; 2, 3, 4)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int device = -1;
@@ -586,6 +599,33 @@ struct HipBackend {
         check_range(r0, r1, ncols);
         if (r1 == r0) return;
         Scope sc(this, fam);
+        if constexpr (Marches<F>::value) {
+            const long long n = (long long)(r1 - r0) * ncols;
+            if (opt_march > 0 || (opt_march < 0 && n >= (1LL << 25))) {
+                const int tiles_x = (ncols + 64 * kMarchWaves - 1) / (64 * kMarchWaves);
+                int seg = opt_march_rows > 0 ? opt_march_rows : F::kMarchRows;
+                // enough workgroups for every compute unit to see many: shorter segments on slabs with few rows
+                while (opt_march_rows <= 0 && seg > 8 && (long long)tiles_x * ((r1 - r0 + seg - 1) / seg) < 16LL * num_cus)
+                    seg /= 2;
+                const long long nt = (long long)tiles_x * ((r1 - r0 + seg - 1) / seg);
+                if (nt > 0x7fffffffLL) throw std::runtime_error("mesh too large for the tile index");
+                if (f.g.nrows < 1 || r0 < 0 || r1 > f.g.nrows || ncols > f.g.ld) throw std::runtime_error("bad marching range");
+                // register budget: the functor's own choice unless an option overrides it.  Three builds of
+                // the kernel: 2 waves per SIMD with the next row requested a row ahead, 3 and 4 without.
+                const int occ = opt_march_occ > 0 ? opt_march_occ : F::kMarchOcc;
+                if (occ <= 2)
+                    hipLaunchKernelGGL((k_march<F, 2, true>), dim3((unsigned)nt), dim3(64, kMarchWaves), 0, stream, f, r0, r1,
+                                       ncols, seg, tiles_x);
+                else if (occ == 3)
+                    hipLaunchKernelGGL((k_march<F, 3, false>), dim3((unsigned)nt), dim3(64, kMarchWaves), 0, stream, f, r0, r1,
+                                       ncols, seg, tiles_x);
+                else
+                    hipLaunchKernelGGL((k_march<F, 4, false>), dim3((unsigned)nt), dim3(64, kMarchWaves), 0, stream, f, r0, r1,
+                                       ncols, seg, tiles_x);
+                TEDD_HIP(hipGetLastError());
+                return;
+            }
+        }
         dim3 block(kTileX, kTileY), grid((ncols + kTileX - 1) / kTileX, (r1 - r0 + kTileY - 1) / kTileY);
         hipLaunchKernelGGL(k_nodes<F>, grid, block, 0, stream, f, r0, r1, ncols);
         TEDD_HIP(hipGetLastError());

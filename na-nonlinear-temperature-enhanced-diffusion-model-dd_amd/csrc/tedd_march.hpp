@@ -1,0 +1,150 @@
+// Marching launcher of the 5-point node functors for gfx950.
+//
+// The plain launcher (k_nodes) gives every node a thread that loads the node and its four neighbours
+// of every stencil array: each row of such an array is requested three times (as row i-1, i, i+1 of
+// three different workgroup rows), and whether the second and third request is served on chip is left
+// to the caches -- on a mesh far larger than them a quarter of it is not.
+//
+// Here a wavefront owns 64 consecutive columns and marches down a segment of rows.  Lanes are columns.
+// Of every stencil array the wave keeps rows i-1, i, i+1 in registers and rolls them: each row is loaded
+// from memory ONCE per segment (plus the two rows that border the segment), as one 512-byte request per
+// wave.  The neighbours at j-1 / j+1 come from the adjacent lanes by DPP wave shifts; only lanes 0 and 63
+// need a value from outside the wave, which one two-lane load per row and array supplies.  Arrays read at
+// the node alone (forcing values, cs) are loaded once, non-temporally.  W waves of a workgroup stand side
+// by side (64 W columns), and workgroups are dealt to the XCDs in contiguous runs of tiles, so that the
+// lines shared across wave and workgroup edges are found in the same L2.
+//
+// A functor F that marches provides
+//   static constexpr int NS, NC;          number of stencil arrays / of arrays read at the node alone
+//   const double* sptr(k), cptr(k);       those arrays (cptr may be null: reads as 0)
+//   GridDev g;
+//   void node(li, j, Geo, const St5 s[NS], const double cv[NC]);   the node body on register values
+// and performs exactly the arithmetic of its operator()(li, j): results are bit-identical.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "tedd_nodes.hpp"
+
+namespace tedd {
+
+// value of the lane below / above with `edge` (the wave's own lane 0 / lane 63 copy) standing in at the
+// end of the wave: lane 0 holds u[j-1] in edge, lane 63 holds u[j+1]
+__device__ __forceinline__ double lane_below_or(double v, double edge) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(edge), lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_above_or(double v, double edge) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(edge), lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int kMarchWaves = 4;  // waves side by side in a workgroup: 256 columns
+
+// OCC: waves per SIMD the register budget is set for.  AHEAD: request everything the next row needs before
+// the present row is computed (more registers; for kernels that run at two waves per SIMD).
+template <class F, int OCC, bool AHEAD>
+__global__ void __launch_bounds__(64 * kMarchWaves) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
+k_march(const F f, int r0, int r1, int ncols, int seg_rows, int tiles_x) {
+    constexpr int NS = F::NS, NC = F::NC;
+    const GridDev& g = f.g;
+    const int lane = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+
+    // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2); every XCD gets a
+    // contiguous run of tiles (x fastest), so that the lines two neighbouring tiles share are found there
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q = nb / 8, rem = nb % 8, xcd = bid % 8;
+    const int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
+    const int ty = t / tiles_x, tx = t % tiles_x;
+
+    const int j = (tx * kMarchWaves + wave) * 64 + lane;
+    const int ra = r0 + ty * seg_rows;
+    const int rb = min(ra + seg_rows, r1);
+    if ((tx * kMarchWaves + wave) * 64 >= ncols) return;  // (whole wave out of the mesh)
+    const bool col_ok = j < ncols;
+    const unsigned jc = (unsigned)min(j, ncols - 1);  // (unsigned: 32-bit lane offsets on scalar row bases)
+    const int rmax = g.nrows - 1;
+    // column metrics are the same for every row of the march
+    const double rks = g.rk[jc], rkn = g.rk[min(jc + 1u, (unsigned)ncols - 1u)], rkm = g.rkm[jc];
+    // the one value per row and array a wave needs from outside: column j-1 for lane 0, j+1 for lane 63
+    const bool edge_lane = (lane == 0 && jc >= 1u) || (lane == 63 && jc + 1u < (unsigned)ncols);
+    const unsigned je = (lane == 0) ? (jc >= 1u ? jc - 1u : 0u) : jc + 1u;
+
+    const double* sp[NS];
+    const double* cp[NC];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) sp[k] = f.sptr(k);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) cp[k] = f.cptr(k);
+
+    // (row bases are wave-uniform: scalar registers; the lanes add a 32-bit column offset)
+    auto row_of = [&](int li) { return (size_t)min(max(li, 0), rmax) * g.ld; };
+    double w[NS], c[NS], e[NS], edge[NS], cv[NC];
+    {
+        const size_t ow = row_of(ra - 1), oc = row_of(ra), oe = row_of(ra + 1);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            w[k] = (sp[k] + ow)[jc];
+            c[k] = (sp[k] + oc)[jc];
+            e[k] = (sp[k] + oe)[jc];
+            edge[k] = edge_lane ? (sp[k] + oc)[je] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) cv[k] = cp[k] ? __builtin_nontemporal_load(cp[k] + oc + jc) : 0.0;
+    }
+    for (int li = ra; li < rb; ++li) {
+        // AHEAD: everything the NEXT row needs is requested before this row is computed: row li+2 of the
+        // stencil arrays, the edge values and the node-only arrays of row li+1 (clamped past the end of the
+        // segment: the values are then unused); the wave waits for them only when it rolls its registers.
+        // Otherwise row li+1 of the stencil arrays is requested at the top of row li, which needs it.
+        const size_t on = row_of(li + 1), on2 = row_of(li + 2);
+        double e2[NS], edge_n[NS], cv_n[NC];
+        if (AHEAD) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) e2[k] = (sp[k] + on2)[jc];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) edge_n[k] = edge_lane ? (sp[k] + on)[je] : 0.0;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) cv_n[k] = cp[k] ? __builtin_nontemporal_load(cp[k] + on + jc) : 0.0;
+        } else if (li > ra) {
+            const size_t oc = row_of(li);
+#pragma unroll
+            for (int k = 0; k < NS; ++k) e[k] = (sp[k] + on)[jc];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) edge[k] = edge_lane ? (sp[k] + oc)[je] : 0.0;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) cv[k] = cp[k] ? __builtin_nontemporal_load(cp[k] + oc + jc) : 0.0;
+        }
+        St5 s[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            s[k].c = c[k];
+            s[k].e = e[k];
+            s[k].w = w[k];
+            s[k].n = lane_above_or(c[k], edge[k]);
+            s[k].s = lane_below_or(c[k], edge[k]);
+        }
+        const int lic = min(li, rmax);
+        const Geo ge{g.rh[lic], g.rh[min(lic + 1, rmax)], g.rhm[lic], rks, rkn, rkm};
+        if (col_ok) f.node(li, j, ge, s, cv);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            w[k] = c[k];
+            c[k] = e[k];
+            if (AHEAD) {
+                e[k] = e2[k];
+                edge[k] = edge_n[k];
+            }
+        }
+        if (AHEAD) {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) cv[k] = cv_n[k];
+        }
+    }
+}
+
+}  // namespace tedd

@@ -28,7 +28,9 @@ TEDD_HD bool is_interior(const GridDev& g, int li, int j) {
     const int i = g.i0 + li;
     return i >= 1 && i <= g.N - 1 && j >= 1 && j <= g.M - 1;
 }
-TEDD_HD size_t at(const GridDev& g, int li, int j) { return (size_t)li * g.ld + j; }
+// (column as unsigned: callers pass 0 <= j < ncols, and a zero-extended 32-bit column offset on top of a
+// row base lets the device address the node from a scalar base register)
+TEDD_HD size_t at(const GridDev& g, int li, int j) { return (size_t)li * g.ld + (unsigned)j; }
 TEDD_HD Geo geo_at(const GridDev& g, int li, int j) {
     return Geo{g.rh[li], g.rh[li + 1], g.rhm[li], g.rk[j], g.rk[j + 1], g.rkm[j]};
 }
@@ -83,16 +85,13 @@ struct F5 {
     double cp, T, cl, cd, cs;
 };
 
-// The semi-discrete field F(S, t) at a node given the forcing values (prob1base.py:2599-2672).
+// The semi-discrete field F(S, t) at a node given the forcing values (prob1base.py:2599-2672), from the
+// node's stencil values (however the caller got them: memory, or the registers of a marching wave).
 template <int REACT>
-TEDD_HD F5 node_field(const ModelC& m, const GridDev& g, const Fields5& S, const Forcing5& f, int li, int j,
-                      bool interior) {
+TEDD_HD F5 node_field_vals(const ModelC& m, const Geo& ge, const St5& cp, const St5& T, const St5& cl, const St5& cd,
+                           double cs, const Forcing5& f, bool interior) {
     F5 F{f.fcp, f.fT, f.fcl, f.fcd, 0.0};
     if (interior) {
-        const Geo ge = geo_at(g, li, j);
-        const St5 cp = load5(S.v[VAR_CP], g, li, j), T = load5(S.v[VAR_T], g, li, j);
-        const St5 cl = load5(S.v[VAR_CL], g, li, j), cd = load5(S.v[VAR_CD], g, li, j);
-        const double cs = S.v[VAR_CS][at(g, li, j)];
         const double R = reaction<REACT>(m, cl.c, cd.c, cs);
         F.cp += rhs_cp(m, cp.c, T.c, cl.c);
         F.T += rhs_T(m, ge, T, cp.c);
@@ -108,6 +107,15 @@ TEDD_HD F5 node_field(const ModelC& m, const GridDev& g, const Fields5& S, const
         }
     }
     return F;
+}
+template <int REACT>
+TEDD_HD F5 node_field(const ModelC& m, const GridDev& g, const Fields5& S, const Forcing5& f, int li, int j,
+                      bool interior) {
+    if (!interior) return F5{f.fcp, f.fT, f.fcl, f.fcd, 0.0};
+    const Geo ge = geo_at(g, li, j);
+    const St5 cp = load5(S.v[VAR_CP], g, li, j), T = load5(S.v[VAR_T], g, li, j);
+    const St5 cl = load5(S.v[VAR_CL], g, li, j), cd = load5(S.v[VAR_CD], g, li, j);
+    return node_field_vals<REACT>(m, ge, cp, T, cl, cd, S.v[VAR_CS][at(g, li, j)], f, true);
 }
 
 // ------------------------------------------------------------------------------------
@@ -180,10 +188,6 @@ struct PredictFn {
         const F5 F = node_field<REACT>(m, g, S, fa, li, j, in);
         const double cp0 = S.v[VAR_CP][c], T0 = S.v[VAR_T][c], cl0 = S.v[VAR_CL][c], cd0 = S.v[VAR_CD][c],
                      cs0 = S.v[VAR_CS][c];
-        const double YTv = dt * F.T + 2.0 * T0;
-        put_once(YT + c, YTv);
-        put_once(Ycl + c, dt * F.cl + 2.0 * cl0);
-        put_once(Ycd + c, dt * F.cd + 2.0 * cd0);
         // forcing at t1: only fcp (cell average) and fcs are needed here
         double fcp1, fcs1, fT1 = 0.0;
         if (CASE == CASE_STREAM && FCASE != CASE_STREAM) {
@@ -208,6 +212,23 @@ struct PredictFn {
             if (fcp_t0_out) fcp_t0_out[c] = fa.fcp;
             if (fcp_t1_out) fcp_t1_out[c] = fcp1;
         }
+        St5 T{T0, 0.0, 0.0, 0.0, 0.0};
+        Geo ge{};
+        if (bT && in) {
+            ge = geo_at(g, li, j);
+            T = load5(S.v[VAR_T], g, li, j);
+        }
+        finish(c, in, ge, F, fa, cp0, T, cl0, cd0, cs0, fcp1, fcs1, fT1);
+    }
+    // Everything after the field evaluation: Y, the Heun predictors, b_T and the corrector parts.
+    // T: lagged T at the node and (where b_T is wanted, interior nodes) its four neighbours.
+    TEDD_HD void finish(size_t c, bool in, const Geo& ge, const F5& F, const Forcing5& fa, double cp0, const St5& T,
+                        double cl0, double cd0, double cs0, double fcp1, double fcs1, double fT1) const {
+        const double T0 = T.c;
+        const double YTv = dt * F.T + 2.0 * T0;
+        put_once(YT + c, YTv);
+        put_once(Ycl + c, dt * F.cl + 2.0 * cl0);
+        put_once(Ycd + c, dt * F.cd + 2.0 * cd0);
         // Heun for cp (other fields frozen at t0)
         const double cps = cp0 + dt * F.cp;
         const double Fcps = fcp1 + (in ? rhs_cp(m, cps, T0, cl0) : 0.0);
@@ -216,8 +237,6 @@ struct PredictFn {
         if (bT) {  // same arithmetic as newton_rhs_value<VAR_T> / newton_row<VAR_T>
             double bv = 0.0;
             if (in) {
-                const Geo ge = geo_at(g, li, j);
-                const St5 T = load5(S.v[VAR_T], g, li, j);
                 const double r = YTv - (2.0 * T.c - dt * (fT1 + rhs_T(m, ge, T, cp1v)));
                 bv = tedd_div(r, 2.0 - dt * jac_T_FT(m, ge, cp1v).c);
             }
@@ -226,7 +245,7 @@ struct PredictFn {
         // Heun for cs
         double v;
         {
-#pragma clang fp contract(off)  // (see node_field)
+#pragma clang fp contract(off)  // (see node_field_vals)
             const double css = cs0 + dt * F.cs;
             const double Fcss = in ? (fcs1 - reaction<REACT>(m, cl0, cd0, css)) : 0.0;
             v = cs0 + (0.5 * dt) * (F.cs + Fcss);
@@ -244,6 +263,24 @@ struct PredictFn {
             const double b0 = -m.Kd * (m.Sd - cd0) * (1.0 + cl0);
             put_once(ycs + c, in ? (1.0 + h * b0) * cs0 + h * (fa.fcs + fcs1) : 0.0);
         }
+    }
+
+    // ---- interface of the marching launcher (tedd_march.hpp), array-fed forcing only: the arrays a node
+    // reads with its four neighbours, the arrays it reads at the node alone (a null pointer reads as 0),
+    // and the node body on values the wave holds in registers
+    static constexpr bool kMarches = (CASE == CASE_STREAM && FCASE == CASE_STREAM);
+    // measured best at 16384^2: two waves per SIMD (the body needs ~180 registers) and 128-row segments
+    static constexpr int kMarchOcc = 2, kMarchRows = 128;
+    static constexpr int NS = 4, NC = 9;
+    TEDD_HD const double* sptr(int k) const { return S.v[k]; }  // cp, T, cl, cd
+    TEDD_HD const double* cptr(int k) const {
+        return k == 0 ? S.v[VAR_CS] : k <= 5 ? f0.f[k - 1] : k == 6 ? f1.f[0] : k == 7 ? f1.f[4] : (bT ? f1.f[1] : nullptr);
+    }
+    TEDD_HD void node(int li, int j, const Geo& ge, const St5* s, const double* cv) const {
+        const bool in = is_interior(g, li, j);
+        const Forcing5 fa{cv[1], cv[2], cv[3], cv[4], cv[5]};
+        const F5 F = node_field_vals<REACT>(m, ge, s[0], s[1], s[2], s[3], cv[0], fa, in);
+        finish(at(g, li, j), in, ge, F, fa, s[0].c, s[1], s[2].c, s[3].c, cv[0], cv[6], cv[7], cv[8]);
     }
 };
 
@@ -264,29 +301,20 @@ struct NewtonIn {
 // (-1,0) ones on the (i,j-1) diagonal (prob1base.py:3097,3099); that is reproduced here.
 // D_pre (optional): the face diffusivities (Dl for cl, Dd for cd) if the caller already has them.
 template <int VAR, int REACT>
-TEDD_HD void newton_row(const ModelC& m, const GridDev& g, const NewtonIn& a, int li, int j, double dt,
-                        double& diag, double& oe, double& ow, double& on, double& os, const Face4* D_pre = nullptr) {
-    const Geo ge = geo_at(g, li, j);
-    const size_t c = at(g, li, j);
+TEDD_HD void newton_row_vals(const ModelC& m, const Geo& ge, double dt, double cp_c, double T_e, double T_w,
+                             const Face4& D, double cl_c, double cs_c, double& diag, double& oe, double& ow, double& on,
+                             double& os) {
     Coef5 r;
     if (VAR == VAR_T) {
-        r = jac_T_FT(m, ge, a.cp1[c]);
+        r = jac_T_FT(m, ge, cp_c);
     } else if (VAR == VAR_CL) {
-        const St5 cp = load5(a.cp1, g, li, j);
         St5 T;
         T.c = 0.0; T.n = 0.0; T.s = 0.0;
-        T.e = a.To[c + g.ld];
-        T.w = a.To[c - g.ld];
-        r = jac_cl_Fcl(m, ge, D_pre ? *D_pre : faces_Dl(m, cp), T, cp.c, 1.0, 1.0);
+        T.e = T_e;
+        T.w = T_w;
+        r = jac_cl_Fcl(m, ge, D, T, cp_c, 1.0, 1.0);
     } else {
-        Face4 D;
-        if (D_pre) {
-            D = *D_pre;
-        } else {
-            const St5 cp = load5(a.cp1, g, li, j), T = load5(a.To, g, li, j);
-            D = faces_Dd(m, cp, T);
-        }
-        r = jac_cd_Fcd<REACT>(m, ge, D, a.clo[c], a.cs1[c]);
+        r = jac_cd_Fcd<REACT>(m, ge, D, cl_c, cs_c);
         const double t = r.w;  // reference quirk: W and S coefficients exchanged in the cd matrix
         r.w = r.s;
         r.s = t;
@@ -297,12 +325,65 @@ TEDD_HD void newton_row(const ModelC& m, const GridDev& g, const NewtonIn& a, in
     on = dt * r.n;
     os = dt * r.s;
 }
+template <int VAR, int REACT>
+TEDD_HD void newton_row(const ModelC& m, const GridDev& g, const NewtonIn& a, int li, int j, double dt,
+                        double& diag, double& oe, double& ow, double& on, double& os, const Face4* D_pre = nullptr) {
+    const Geo ge = geo_at(g, li, j);
+    const size_t c = at(g, li, j);
+    if (VAR == VAR_T) {
+        newton_row_vals<VAR, REACT>(m, ge, dt, a.cp1[c], 0.0, 0.0, Face4{}, 0.0, 0.0, diag, oe, ow, on, os);
+    } else if (VAR == VAR_CL) {
+        const St5 cp = load5(a.cp1, g, li, j);
+        newton_row_vals<VAR, REACT>(m, ge, dt, cp.c, a.To[c + g.ld], a.To[c - g.ld], D_pre ? *D_pre : faces_Dl(m, cp), 0.0,
+                                    0.0, diag, oe, ow, on, os);
+    } else {
+        Face4 D;
+        if (D_pre) {
+            D = *D_pre;
+        } else {
+            const St5 cp = load5(a.cp1, g, li, j), T = load5(a.To, g, li, j);
+            D = faces_Dd(m, cp, T);
+        }
+        newton_row_vals<VAR, REACT>(m, ge, dt, 0.0, 0.0, 0.0, D, a.clo[c], a.cs1[c], diag, oe, ow, on, os);
+    }
+}
 
 // Right-hand side of the Newton system for v at an interior node (prob1base.py:3025-3036,
 // 3068-3073, 3102-3108): rhs_T = Y_T - (2 T - dt F_T(S',t1)); rhs_cl = Y_cl - 2 cl + dt F_cl(S',t1)
 // + dt (dFcl/dT)(Tn - T); rhs_cd = Y_cd - 2 cd + dt F_cd(S',t1) + dt (dFcd/dT)(Tn - T)
 // + dt (dFcd/dcl)(cln - cl).
 // D_out (optional): receives the face diffusivities the right-hand side evaluated (cl, cd).
+// From values (cl and cd systems): fv forcing value, Y = Y_v, u the lagged unknown with its neighbours, Tn the
+// new T with its neighbours (cl: only e, w are used), w_ok / e_ok: 0 where node (i-1,j) / (i+1,j) is a boundary node.
+template <int VAR, int REACT>
+TEDD_HD double newton_rhs_vals(const ModelC& m, const Geo& ge, double dt, double fv, double Y, double w_ok, double e_ok,
+                               const St5& cp, const St5& T, const St5& u, const St5& Tn, double clc, double csc,
+                               double clnc, Face4* D_out) {
+    double r;
+    if (VAR == VAR_CL) {
+        const St5& cl = u;
+        const Face4 Dl = faces_Dl(m, cp);
+        if (D_out) *D_out = Dl;
+        const double F = fv + rhs_cl(m, ge, Dl, T, cl, cp.c);
+        // coupling  dt * (dFcl/dT) (Tn - To), boundary entries of (Tn - To) dropped
+        const Coef5 k = jac_T_Fcl(m, ge, cl, w_ok, e_ok);
+        const double ww = Tn.w - T.w, we = Tn.e - T.e;
+        r = Y - 2.0 * cl.c + dt * F + dt * (k.e * we + k.w * ww);
+    } else {
+        const St5& cd = u;
+        Face4 Dd, dDd;
+        faces_Dd_pair(m, cp, T, Dd, dDd);
+        if (D_out) *D_out = Dd;
+        const double F = fv + rhs_cd_diffusion(ge, Dd, cd) + reaction<REACT>(m, clc, cd.c, csc);
+        // coupling with (Tn - To) keeps the boundary entries of the increment
+        const Coef5 k = jac_T_Fcd(ge, dDd, cd);
+        const double JTw = k.c * (Tn.c - T.c) + k.e * (Tn.e - T.e) + k.w * (Tn.w - T.w) + k.n * (Tn.n - T.n) +
+                           k.s * (Tn.s - T.s);
+        const double Jclw = jac_cl_Fcd_diag<REACT>(m, cd.c, csc) * (clnc - clc);
+        r = Y - 2.0 * cd.c + dt * F + dt * JTw + dt * Jclw;
+    }
+    return r;
+}
 template <int VAR, int CASE, int REACT>
 TEDD_HD double newton_rhs_value(const GridDev& g, const ModelC& m, const MmsTabs& tb, const ForcingSrc& f1,
                                 const NewtonIn& a, double dt, int li, int j, Face4* D_out = nullptr) {
@@ -315,37 +396,21 @@ TEDD_HD double newton_rhs_value(const GridDev& g, const ModelC& m, const MmsTabs
         const MmsPt p = mms_node<CASE>(m, f1.tm, tb, li, j);
         fv = (VAR == VAR_T) ? mms_fT(m, p) : (VAR == VAR_CL) ? mms_fcl(m, p) : mms_fcd<REACT>(m, p);
     }
-    double r;
     if (VAR == VAR_T) {
         const St5 T = load5(a.To, g, li, j);
-        r = a.YT[c] - (2.0 * T.c - dt * (fv + rhs_T(m, ge, T, a.cp1[c])));
-    } else if (VAR == VAR_CL) {
-        const St5 cp = load5(a.cp1, g, li, j), T = load5(a.To, g, li, j), cl = load5(a.clo, g, li, j);
-        const Face4 Dl = faces_Dl(m, cp);
-        if (D_out) *D_out = Dl;
-        const double F = fv + rhs_cl(m, ge, Dl, T, cl, cp.c);
-        // coupling  dt * (dFcl/dT) (Tn - To), boundary entries of (Tn - To) dropped
-        const int i = g.i0 + li;
-        const double w_ok = (i > 1) ? 1.0 : 0.0, e_ok = (i < g.N - 1) ? 1.0 : 0.0;
-        const Coef5 k = jac_T_Fcl(m, ge, cl, w_ok, e_ok);
-        const double ww = a.Tn[c - g.ld] - T.w, we = a.Tn[c + g.ld] - T.e;
-        r = a.Ycl[c] - 2.0 * cl.c + dt * F + dt * (k.e * we + k.w * ww);
-    } else {
-        const St5 cp = load5(a.cp1, g, li, j), T = load5(a.To, g, li, j), cd = load5(a.cdo, g, li, j);
-        const double clc = a.clo[c], csc = a.cs1[c];
-        Face4 Dd, dDd;
-        faces_Dd_pair(m, cp, T, Dd, dDd);
-        if (D_out) *D_out = Dd;
-        const double F = fv + rhs_cd_diffusion(ge, Dd, cd) + reaction<REACT>(m, clc, cd.c, csc);
-        // coupling with (Tn - To) keeps the boundary entries of the increment
-        const Coef5 k = jac_T_Fcd(ge, dDd, cd);
-        const St5 Tn = load5(a.Tn, g, li, j);
-        const double JTw = k.c * (Tn.c - T.c) + k.e * (Tn.e - T.e) + k.w * (Tn.w - T.w) + k.n * (Tn.n - T.n) +
-                           k.s * (Tn.s - T.s);
-        const double Jclw = jac_cl_Fcd_diag<REACT>(m, cd.c, csc) * (a.cln[c] - clc);
-        r = a.Ycd[c] - 2.0 * cd.c + dt * F + dt * JTw + dt * Jclw;
+        return a.YT[c] - (2.0 * T.c - dt * (fv + rhs_T(m, ge, T, a.cp1[c])));
     }
-    return r;
+    const int i = g.i0 + li;
+    const double w_ok = (i > 1) ? 1.0 : 0.0, e_ok = (i < g.N - 1) ? 1.0 : 0.0;
+    const St5 cp = load5(a.cp1, g, li, j), T = load5(a.To, g, li, j);
+    if (VAR == VAR_CL) {
+        const St5 cl = load5(a.clo, g, li, j);
+        St5 Tn{0.0, a.Tn[c + g.ld], a.Tn[c - g.ld], 0.0, 0.0};
+        return newton_rhs_vals<VAR_CL, REACT>(m, ge, dt, fv, a.Ycl[c], w_ok, e_ok, cp, T, cl, Tn, 0.0, 0.0, 0.0, D_out);
+    }
+    const St5 cd = load5(a.cdo, g, li, j), Tn = load5(a.Tn, g, li, j);
+    return newton_rhs_vals<VAR_CD, REACT>(m, ge, dt, fv, a.Ycd[c], w_ok, e_ok, cp, T, cd, Tn, a.clo[c], a.cs1[c], a.cln[c],
+                                          D_out);
 }
 
 // K_rhs: right-hand side of the Newton system for v and the first Jacobi iterate
@@ -372,6 +437,38 @@ struct NewtonRhsFn {
         double diag, oe, ow, on, os;
         newton_row<VAR, REACT>(m, g, a, li, j, dt, diag, oe, ow, on, os, VAR == VAR_T ? nullptr : &D);
         if (rhs) rhs[c] = r;  // not needed by solvers that iterate on rhs/diag
+        d1[c] = tedd_div(r, diag);
+    }
+
+    // ---- interface of the marching launcher (tedd_march.hpp): cl and cd systems with array-fed forcing
+    static constexpr bool kMarches = (CASE == CASE_STREAM && VAR != VAR_T);
+    static constexpr int kMarchOcc = (VAR == VAR_CL) ? 4 : 3, kMarchRows = 64;  // (measured best at 16384^2)
+    static constexpr int NS = 4;                       // cp*, lagged T, lagged unknown, new T
+    static constexpr int NC = (VAR == VAR_CL) ? 2 : 5;  // Y, forcing | + lagged cl, cs*, new cl
+    TEDD_HD const double* sptr(int k) const {
+        return k == 0 ? a.cp1 : k == 1 ? a.To : k == 2 ? (VAR == VAR_CL ? a.clo : a.cdo) : a.Tn;
+    }
+    TEDD_HD const double* cptr(int k) const {
+        if (VAR == VAR_CL) return k == 0 ? a.Ycl : f1.f[VAR_CL];
+        return k == 0 ? a.Ycd : k == 1 ? f1.f[VAR_CD] : k == 2 ? a.clo : k == 3 ? a.cs1 : a.cln;
+    }
+    TEDD_HD void node(int li, int j, const Geo& ge, const St5* s, const double* cv) const {
+        const size_t c = at(g, li, j);
+        if (!is_interior(g, li, j)) {
+            if (rhs) rhs[c] = 0.0;
+            d1[c] = 0.0;
+            return;
+        }
+        const int i = g.i0 + li;
+        const double w_ok = (i > 1) ? 1.0 : 0.0, e_ok = (i < g.N - 1) ? 1.0 : 0.0;
+        Face4 D;
+        const double clc = (VAR == VAR_CD) ? cv[2] : 0.0, csc = (VAR == VAR_CD) ? cv[3] : 0.0;
+        const double clnc = (VAR == VAR_CD) ? cv[4] : 0.0;
+        const double r = newton_rhs_vals<VAR, REACT>(m, ge, dt, cv[1], cv[0], w_ok, e_ok, s[0], s[1], s[2], s[3], clc, csc,
+                                                     clnc, &D);
+        double diag, oe, ow, on, os;
+        newton_row_vals<VAR, REACT>(m, ge, dt, s[0].c, s[1].e, s[1].w, D, clc, csc, diag, oe, ow, on, os);
+        if (rhs) rhs[c] = r;
         d1[c] = tedd_div(r, diag);
     }
 };

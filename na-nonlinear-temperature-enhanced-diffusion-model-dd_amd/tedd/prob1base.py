@@ -1243,11 +1243,47 @@ class TimeIntegratorBase(ABC):
         pass
 
 
+# Methods of a field whose work the step kernels do themselves: the reference's integrators call them on the
+# field object (src/prob1base.py:2885-3149), so a test or a user can change a step by overriding one
+# (tests/test_time_integrator_hcs_triple.py:208-226 overrides Fcs).  The kernels do not call back into Python:
+# an override would be ignored, so it is refused.  (Re-assigned forcing callables f* are honoured: streamed.)
+_KERNEL_METHODS = (
+    "Fcp", "FT", "Fcl", "Fcd", "Fcs",
+    "delT_ab_FT_ij", "delT_ab_Fcl_ij", "delcl_ab_Fcl_ij", "delT_ab_Fcd_ij", "delcl_ab_Fcd_ij", "delcd_ab_Fcd_ij",
+    "delT_Fcl_at_w", "delT_Fcd_at_w", "delcl_Fcd_at_w",
+    "cscd_reaction_T", "cscd_reaction_cl", "cscd_reaction_cd", "cscd_reaction_cp", "cscd_reaction_cs",
+    "cscd_reaction_term", "delT_ab_cscd_reaction_ij", "delcl_ab_cscd_reaction_ij", "delcd_ab_cscd_reaction_ij",
+)
+
+
+def _overridden_kernel_methods(field):
+    """Names of kernel-implemented methods that `field` (its instance dictionary or a class outside this module)
+    replaces."""
+    found = []
+    for name in _KERNEL_METHODS:
+        if name in vars(field):
+            found.append(name)
+            continue
+        for klass in type(field).__mro__:
+            if name in vars(klass):
+                if klass.__module__ != __name__:
+                    found.append(name)
+                break
+    return found
+
+
 def _require_device_field(field):
     if not isinstance(field, _DeviceField):
         raise NotImplementedError(
             f"{type(field).__name__} is not a device field: the integrators of this package run on the GPU and "
             "have no CPU fallback")
+    replaced = _overridden_kernel_methods(field)
+    if replaced:
+        raise NotImplementedError(
+            f"{type(field).__name__} overrides {', '.join(replaced)}: the step runs in device kernels that have the "
+            "field, its Jacobian stencils and the interaction laws built in and do not call back into Python, so the "
+            "override would be ignored. Express the change through the forcing callables f* (they may be re-assigned "
+            "and are then streamed to the device) or through the model constants.")
     return field
 
 

@@ -945,3 +945,42 @@ def check_error_behaviour():
     dummy.model, dummy.grid = model, trial.grid
     with pytest.raises(NotImplementedError):
         p1.ForwardEulerIntegrator(dummy).step(S0, t0=0.0, dt=1e-3)
+
+
+def check_overridden_field_methods_are_refused():
+    """The reference's tests change a step by overriding a method of the field (Fcs in
+    tests/test_time_integrator_hcs_triple.py:208-226, forcing callables patched onto a live field in
+    tests/test_time_integrator_hcs_triple_full_step.py:189-196).  The device step cannot call back into Python:
+    an overridden field method is refused by name (subclass or instance attribute), for every integrator and for
+    the pieces of a step; a re-assigned forcing callable is honoured (streamed to the device)."""
+    model = model_of("nb_a")
+    grid = p1.make_uniform_grid(N=6, M=6)
+    case = p1mc.MMSCaseExpSin(grid, model=model)
+
+    class FieldWithFcs(p1.SemiDiscreteField_HCsTriple):
+        def Fcs(self, at_t, t):
+            return np.zeros(self.grid.full_shape)
+
+    ft = p1.ForcingTerms_HCsTriple(mms_case=case, model=model)
+    S0 = p1.state_from_mms_when(mms_case=case, t=0.0, grid=grid)
+    sub = FieldWithFcs(grid=grid, model=model, forcing_terms=ft)
+    for integ in (p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_HCsTriple(sub), p1.ForwardEulerIntegrator(sub)):
+        with pytest.raises(NotImplementedError, match="overrides Fcs"):
+            integ.step(S0, t0=0.0, dt=1e-3)
+    with pytest.raises(NotImplementedError, match="overrides Fcs"):
+        p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_HCsTriple(sub).initial_cs_pred(S0, 0.0, dt=1e-3)
+    # the same on an instance, and for the interaction law and a Jacobian stencil
+    plain = p1.SemiDiscreteField_RegHCsTriple(grid=grid, model=model, regularization_factor=50.0,
+                                              forcing_terms=p1.ForcingTerms_RegHCsTriple(mms_case=case, model=model,
+                                                                                        regularization_factor=50.0))
+    integ = p1.P_ModifiedEuler_C_Trapezoidal_TimeIntegrator_RegHCsTriple(plain, regularization_factor=50.0)
+    S1 = integ.step(S0, t0=0.0, dt=1e-3)                       # untouched field: runs
+    plain.cscd_reaction_cs = lambda cs: cs
+    plain.delcd_ab_Fcd_ij = lambda state, *, a, b: 0.0
+    with pytest.raises(NotImplementedError, match="delcd_ab_Fcd_ij.*cscd_reaction_cs|cscd_reaction_cs.*delcd_ab_Fcd_ij"):
+        integ.step(S0, t0=0.0, dt=1e-3)
+    del plain.cscd_reaction_cs, plain.delcd_ab_Fcd_ij
+    # a re-assigned forcing callable is not an override of a kernel: it changes the step
+    plain.fcs = lambda t, xx, yy: np.full(grid.full_shape, 0.25)
+    S2 = integ.step(S0, t0=0.0, dt=1e-3)
+    assert np.max(np.abs(S2.cs - S1.cs)) > 1e-5

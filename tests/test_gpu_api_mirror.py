@@ -18,6 +18,10 @@ def hip_library():
     yield
 
 
+def test_overridden_field_methods_are_refused():
+    ac.check_overridden_field_methods_are_refused()
+
+
 def test_classes_instantiation():
     ac.check_classes_instantiation()
 

@@ -1,0 +1,60 @@
+"""The marching launcher of the stencil kernels (a wavefront walks down 64 columns, stencil rows in registers,
+column neighbours by lane shifts) against the plain one-thread-per-node launcher: the same node bodies on
+the same values, so every result must be bit-identical -- on meshes whose width is not a multiple of the
+wave or of the workgroup, with one-column and one-row remainders, on segments shorter than a workgroup's
+share, for every reaction kind and every register budget of the kernel.  (The plain launcher is what the
+golden-vector tests pin.)"""
+import numpy as np
+import pytest
+
+from tedd import _ffi
+
+pytestmark = pytest.mark.gpu
+
+STRESS = [8.3144621, 1.60217662e-19, 0.11, 0.23, 0.37, 0.19, 2e-2, 3e-2, 0.4, 0.03, 0.2, 1.5, 1e-2, 0.3, 50.0,
+          5e-2, 300.0]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def hip_library():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    _ffi.use_library(_ffi.DEFAULT_LIBRARY)
+    yield
+
+
+def _run(N, M, react, options, row_lo=0, row_hi=None, ghost=0):
+    x = np.linspace(0, 1, N + 1) ** 1.07
+    y = np.linspace(0, 1, M + 1) ** 0.93
+    ctx = _ffi.Context(x, y, STRESS, model_kind=2, reaction_kind=react, eta=30.0, mms_case=_ffi.MMS_PEAKS,
+                       mms_params=(1.0, 10.0), row_lo=row_lo, row_hi=row_hi, ghost=ghost)
+    ctx.set_option("fuse_forcing", 0)      # (array-fed predictor: the variant that marches)
+    for k, v in options.items():
+        ctx.set_option(k, v)
+    ctx.set_state_exact(0.0)
+    ctx.step_pc(0.0, 2e-3, jacobi_sweeps=(5, 4, 3), cs_newton_iterations=3)
+    if ghost == 0:
+        ctx.step_pc(2e-3, 2e-3, jacobi_sweeps=(5, 4, 3), cs_newton_iterations=3)
+    out = ctx.get_state()
+    ctx.close()
+    return out
+
+
+@pytest.mark.parametrize("N,M", [(70, 300), (257, 64), (40, 520), (9, 255), (130, 256)])
+@pytest.mark.parametrize("react", [_ffi.REACT_CSTRIPLE, _ffi.REACT_REGHCSTRIPLE, _ffi.REACT_HCSTRIPLE])
+def test_marching_launcher_is_bit_identical(N, M, react):
+    ref = _run(N, M, react, {"march": 0})
+    for opts in ({"march": 1}, {"march": 1, "march_occ": 2, "march_rows": 8}, {"march": 1, "march_occ": 3, "march_rows": 16},
+                 {"march": 1, "march_occ": 4, "march_rows": 5}):
+        got = _run(N, M, react, opts)
+        for a, b in zip(ref, got):
+            np.testing.assert_array_equal(a, b, err_msg=str(opts))
+
+
+def test_marching_launcher_on_a_slab_with_ghost_rows():
+    """A slab in the middle of the mesh: the launch range starts and ends inside the local rows."""
+    kw = dict(row_lo=40, row_hi=90, ghost=16)
+    ref = _run(150, 200, _ffi.REACT_REGHCSTRIPLE, {"march": 0}, **kw)
+    got = _run(150, 200, _ffi.REACT_REGHCSTRIPLE, {"march": 1, "march_rows": 16}, **kw)
+    for a, b in zip(ref, got):
+        np.testing.assert_array_equal(a[16:-16], b[16:-16])
