@@ -863,6 +863,8 @@ public:
     // Returns false if the record cannot be had (never published, or overwritten).
     bool lagged_record(long long seq, double* upd, double* inc, double* first) {
         if (seq < chain_start || seq < 0 || seq + kRing <= next_seq || seq + 1 >= next_seq) return false;
+        const StepMeta& ms = meta[seq % kRing];
+        if (ms.seq != seq || !(ms.warm[0] || ms.warm[1] || ms.warm[2])) return false;  // (never published)
         volatile double* slot = h_ring + 16 * (seq % kRing);
         const double want = (double)seq;
         for (long long spin = 0; slot[0] != want; ++spin) {
@@ -974,12 +976,16 @@ public:
             const bool have_before = next_seq > chain_start && record_unfolded;
             const StepMeta& mb = meta[(next_seq - 1 + kRing) % kRing];
             ra.fold = (have_before && record_unjudged) ? 1 : 0;
-            ra.ring_slot = have_before ? d_ring + 16 * ((next_seq - 1) % kRing) : nullptr;
+            // (only the record of a warm-started solve is ever read back: choose_sweeps)
+            const bool any_warm = mb.warm[0] || mb.warm[1] || mb.warm[2];
+            ra.ring_slot = (have_before && any_warm) ? d_ring + 16 * ((next_seq - 1) % kRing) : nullptr;
             ra.seq = (double)(next_seq - 1);
             for (int v = 0; v < 3; ++v) ra.tol[v] = have_before ? mb.tol[v] : 0.0;
             ra.clear = 1;
             ra.cs_iters = (react == REACT_REG) ? cs_iters : 0;
-            be.step_prologue(ra);
+            // (carried out by the predictor launch where that is a plain node launch, else by a launch of its own)
+            pending_prologue = ra;
+            have_pending_prologue = true;
         }
         meta[next_seq % kRing] = mt;
         next_seq += 1;
@@ -988,7 +994,9 @@ public:
         for (int v = 0; v < 3; ++v) judged_since_check = judged_since_check || (record_unfolded && mt.tol[v] > 0.0);
         try {
             step_pc_dispatch(p);
+            if (have_pending_prologue) run_pending_prologue();  // (a step without a predictor launch)
         } catch (...) {
+            have_pending_prologue = false;
             // nothing of a failed step may serve a later one
             bT_ready = false;
             predict_makes_f1 = false;
@@ -998,6 +1006,23 @@ public:
             chain_start = next_seq;
             drop_prev();
             throw;
+        }
+    }
+    StepRecordArgs pending_prologue;
+    bool have_pending_prologue = false;
+    void run_pending_prologue() {
+        if (!have_pending_prologue) return;
+        have_pending_prologue = false;
+        be.step_prologue(pending_prologue);
+    }
+    // the predictor launch of a step, carrying the step's prologue where the backend can fold it in
+    template <class F>
+    void launch_predictor(const F& f, int r0, int r1) {
+        if (have_pending_prologue) {
+            have_pending_prologue = false;
+            be.nodes_with_prologue(FAM_PREDICT, f, r0, r1, ncols, pending_prologue);
+        } else {
+            be.nodes(FAM_PREDICT, f, r0, r1, ncols);
         }
     }
     void step_pc_dispatch(const StepParams& p) {
@@ -1111,6 +1136,14 @@ public:
     int opt_strip = 1;      // 1: register-resident solve chain (backends that have it); 0: one launch per sweep
     int opt_strip_hmax = 0;         // sweeps fused per launch (0 = automatic)
     int opt_strip_shape = -1;       // tile shape of the chain: -1 by mesh size and system, 0: 64 rows, 1: 32 rows, 2: 48 rows
+    // single-launch cl / cd chains evaluate their right-hand side themselves: -1 on slabs of at most 4 M nodes
+    // (a launch and five to seven array passes fewer per solve; on large slabs the arithmetic repeated in the
+    // tile halos costs more than the passes: 16384^2, rhs + solve launches 6.75 / 8.66 ms against 6.79 / 9.47 fused)
+    int opt_fuse_rhs = -1;
+    int opt_exact_faces = 0;  // (test hook, see StripArgs::xface)
+    bool fuse_rhs_now() const {
+        return opt_fuse_rhs < 0 ? (size_t)nrows * ncols <= ((size_t)1 << 22) : opt_fuse_rhs != 0;
+    }
     bool bT_ready = false;    // slot DA holds rhs/diag of the next T system (written by the predictor launch)
 
     // Register-resident solve chain (tedd_strip.hpp): b = delta^1 = rhs/diag from the node kernel,
@@ -1146,12 +1179,25 @@ public:
             else
                 r = need({{a.cp1, true}, {a.To, true}, {a.cdo, true}, {a.clo, false}, {a.cs1, false}, {a.Tn, true},
                           {a.cln, false}, {a.Ycd, false}});
+            // a single-launch chain of the cl / cd system on 4-row strips evaluates its right-hand side itself
+            bool fused = false;
+            if constexpr (VAR != VAR_T && CASE == CASE_STREAM) {
+                fused = fuse_rhs_now() && L == 1 && be.strip_can_fuse(VAR, remaining, r.lo, r.hi, ncols, opt_strip_shape);
+            }
             if (VAR == VAR_T && bT_ready) {
                 bT_ready = false;  // b came with the predictor launch
-            } else {
+            } else if (!fused) {
                 NewtonRhsFn<VAR, CASE, REACT> fr{A.g, model, tabs(), f1, a, nullptr, bsc, p.dt};
                 be.nodes(fam_rhs, fr, r.lo, r.hi, ncols);
                 mark(bsc, r);
+            }
+            A.xface = (opt_exact_faces && L == 1 && !fused) ? 1 : 0;
+            if (fused) {
+                // (the launch reads the same arrays with the same stencils as the right-hand-side kernel would,
+                // then sweeps: the valid range follows from both)
+                A.Y = (VAR == VAR_CL) ? a.Ycl : a.Ycd;
+                A.fv = f1.f[VAR];
+                mark(bsc, r);  // stands for b: valid where the right-hand side can be evaluated
             }
             const double* din = u_prev ? nullptr : bsc;
             const double* uo = (VAR == VAR_T) ? a.To : (VAR == VAR_CL) ? a.clo : a.cdo;
@@ -1177,8 +1223,8 @@ public:
                                     {s0, false}, {s1, false}}, ns);
                 A.r0 = r.lo;
                 A.r1 = r.hi;
-                A.b_in = bsc;
-                A.d_in = din;
+                A.b_in = fused ? nullptr : bsc;
+                A.d_in = fused ? nullptr : din;
                 double* dout = lastl ? nullptr : iter[l & 1];
                 A.d_out = dout;
                 A.u_out = lastl ? unew : nullptr;
@@ -1323,7 +1369,7 @@ public:
                         PredictFn<CASE_STREAM, REACT, decltype(fcase)::value> f{
                             g, model, tb, f0, f1c, fields(cur), YT, Ycl, Ycd, cpP, csP, fcp_t0, fcp_t0_out,
                             fcp_t1_out, dt, bT, ncp, ycs, fo};
-                        be.nodes(FAM_PREDICT, f, r.lo, r.hi, ncols);
+                        launch_predictor(f, r.lo, r.hi);
                     };
                     switch (mms_case) {
                         case CASE_POL: launch(std::integral_constant<int, CASE_POL>{}); break;
@@ -1339,7 +1385,7 @@ public:
             if (!launched) {
                 PredictFn<CASE, REACT> f{g, model, tb, f0, f1, fields(cur), YT, Ycl, Ycd, cpP, csP, fcp_t0, fcp_t0_out,
                                          fcp_t1_out, dt, bT, ncp, ycs, Out5{}};
-                be.nodes(FAM_PREDICT, f, r.lo, r.hi, ncols);
+                launch_predictor(f, r.lo, r.hi);
             }
             for (double* q : {YT, Ycl, Ycd, cpP, csP, ncp, ycs}) mark(q, r);
             if (bT) mark(bT, r);
@@ -1605,13 +1651,17 @@ public:
             opt_strip_hmax = (int)value;
         else if (name == "strip_shape")
             opt_strip_shape = (int)value;
+        else if (name == "fuse_rhs")
+            opt_fuse_rhs = value < 0.0 ? -1 : (value != 0.0);
         else if (name == "cache_forcing")
             opt_cache_forcing = value != 0.0;
         else if (name == "fuse_forcing")
             opt_fuse_forcing = value < 0.0 ? -1 : (value != 0.0);
-        else if (name == "march" || name == "march_rows" || name == "march_occ") {
+        else if (name == "march" || name == "march_rows" || name == "march_occ" || name == "exact_faces") {
             if constexpr (Backend::kHasStripSolve) {
-                if (name == "march")
+                if (name == "exact_faces")
+                    opt_exact_faces = value != 0.0;
+                else if (name == "march")
                     be.opt_march = value < 0.0 ? -1 : (value != 0.0);
                 else if (name == "march_rows")
                     be.opt_march_rows = (int)value;

@@ -163,9 +163,8 @@ __global__ void k_cs_init(unsigned long long* gmax, unsigned long long* gmin, in
 // into the sticky worst ratio  last_update / (tol * increment)  per system, publishes that record to a
 // host-visible ring slot (the host reads it two steps later to choose sweep counts, without ever
 // synchronising with the stream), then clears the record of the Newton solves and that of the cs corrector.
-__global__ void k_step_prologue(const StepRecordArgs a, unsigned long long* gmax, unsigned long long* gmin) {
-    const int k = threadIdx.x;
-    __shared__ double rec[16];
+__device__ __forceinline__ void step_prologue_body(const StepRecordArgs& a, unsigned long long* gmax,
+                                                   unsigned long long* gmin, int k, int nthreads, double* rec /*LDS, 16*/) {
     if (k < 16) rec[k] = a.red[k];
     __syncthreads();
     if (k < 3 && a.fold) fold_record(a, rec, k);
@@ -181,11 +180,27 @@ __global__ void k_step_prologue(const StepRecordArgs a, unsigned long long* gmax
     }
     if (a.clear) {
         if (k < 16) a.red[k] = 0.0;
-        for (int q = k; q < a.cs_iters; q += blockDim.x) {
+        for (int q = k; q < a.cs_iters; q += nthreads) {
             gmax[q] = 0ull;
             gmin[q] = 0x7FF0000000000000ull;
         }
     }
+}
+__global__ void k_step_prologue(const StepRecordArgs a, unsigned long long* gmax, unsigned long long* gmin) {
+    __shared__ double rec[16];
+    step_prologue_body(a, gmax, gmin, threadIdx.x, blockDim.x, rec);
+}
+// k_nodes whose first workgroup also carries out the prologue of the step (small meshes: a launch fewer).
+// Nothing else in the launch, and no launch between this one and the solves, touches the records.
+template <class F>
+__global__ void __launch_bounds__(256) k_nodes_pro(const F f, int r0, int r1, int ncols, const StepRecordArgs a,
+                                                  unsigned long long* gmax, unsigned long long* gmin) {
+    __shared__ double rec[16];
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        step_prologue_body(a, gmax, gmin, threadIdx.y * kTileX + threadIdx.x, 256, rec);
+    const int j = blockIdx.x * kTileX + threadIdx.x;
+    const int li = r0 + blockIdx.y * kTileY + threadIdx.y;
+    if (j < ncols && li < r1) f(li, j);
 }
 // number of cs Newton iterations the reference keeps: k+1 for the first k with max|dx_k| < rtol min|x_k|
 __device__ __forceinline__ bool cs_stop_after(const unsigned long long* gmax, const unsigned long long* gmin, int k,
@@ -429,6 +444,28 @@ struct HipBackend {
     void step_prologue(StepRecordArgs a) {
         if (a.cs_iters > 4096) a.cs_iters = 0;  // (refused later, by correct)
         hipLaunchKernelGGL(k_step_prologue, dim3(1), dim3(256), 0, stream, a, d_csstats, d_csstats + 4096);
+        TEDD_HIP(hipGetLastError());
+        if (a.clear) cs_record_clean = a.cs_iters;
+    }
+    // the predictor launch with the step's prologue folded into its first workgroup; where the launch is a
+    // marching one (large slabs) the prologue keeps a launch of its own
+    template <class F>
+    void nodes_with_prologue(int fam, const F& f, int r0, int r1, int ncols, StepRecordArgs a) {
+        check_range(r0, r1, ncols);
+        bool marching = false;
+        if constexpr (Marches<F>::value) {
+            const long long n = (long long)(r1 - r0) * ncols;
+            marching = opt_march > 0 || (opt_march < 0 && n >= (1LL << 25));
+        }
+        if (marching || r1 == r0) {
+            step_prologue(a);
+            nodes(fam, f, r0, r1, ncols);
+            return;
+        }
+        if (a.cs_iters > 4096) a.cs_iters = 0;  // (refused later, by correct)
+        Scope sc(this, fam);
+        dim3 block(kTileX, kTileY), grid((ncols + kTileX - 1) / kTileX, (r1 - r0 + kTileY - 1) / kTileY);
+        hipLaunchKernelGGL(k_nodes_pro<F>, grid, block, 0, stream, f, r0, r1, ncols, a, d_csstats, d_csstats + 4096);
         TEDD_HIP(hipGetLastError());
         if (a.clear) cs_record_clean = a.cs_iters;
     }
@@ -699,50 +736,88 @@ struct HipBackend {
     // the large ones would leave compute units without work (fewer than 2 tiles per unit); otherwise
     // large tiles for T and 48-row tiles for cl and cd (tedd_strip.hpp, StripShape).  A shape whose
     // tile the depth H does not fit falls back to the large one.
-    template <int VAR, int REACT, bool LAST>
-    void solve_strip(int fam, StripArgs A, int ncols, int shape = -1) {
-        if (A.r1 <= A.r0) return;
-        if (A.H < 0 || A.H > 16 || A.nsweeps < 0 || A.nsweeps > A.H) throw std::runtime_error("bad strip-solve depth");
-        if (A.b_in == nullptr || (A.d_in == nullptr && A.u_prev == nullptr))
-            throw std::runtime_error("strip solve needs rhs/diag and a starting iterate");
-        Scope sc(this, fam);
-        const int TIC = kSTile - 2 * strip_col_halo(A.H);
-        A.tiles_x = (ncols + TIC - 1) / TIC;
+    // tile shape of a strip launch of depth H over rows [r0, r1): the caller's choice, or by mesh size and system
+    int strip_shape_for(int var, int H, int r0, int r1, int ncols, int shape) const {
+        const int TIC = kSTile - 2 * strip_col_halo(H);
+        const long long tiles_x = (ncols + TIC - 1) / TIC;
         auto n_tiles = [&](int sh) {
-            const int TIR = strip_tile_rows(sh) - 2 * A.H;
-            return (long long)A.tiles_x * ((A.r1 - A.r0 + TIR - 1) / TIR);
+            const int TIR = strip_tile_rows(sh) - 2 * H;
+            return tiles_x * ((r1 - r0 + TIR - 1) / TIR);
         };
-        const bool small_fits = strip_tile_rows(SHAPE_SMALL) - 2 * A.H >= 8;
-        const bool mid_fits = strip_tile_rows(SHAPE_MID) - 2 * A.H >= 8;
+        const bool small_fits = strip_tile_rows(SHAPE_SMALL) - 2 * H >= 8;
+        const bool mid_fits = strip_tile_rows(SHAPE_MID) - 2 * H >= 8;
         if (shape < 0) {
             if (small_fits && n_tiles(SHAPE_LARGE) < 2LL * num_cus)
                 shape = SHAPE_SMALL;
             else
-                shape = (VAR != VAR_T && A.H <= 8) ? SHAPE_MID : SHAPE_LARGE;
+                shape = (var != VAR_T && H <= 8) ? SHAPE_MID : SHAPE_LARGE;
         }
         if ((shape == SHAPE_SMALL && !small_fits) || (shape == SHAPE_MID && !mid_fits)) shape = SHAPE_LARGE;
-        const long long nt = n_tiles(shape);
+        return shape;
+    }
+    // a single-launch chain of the cl or cd system on 4-row strips can evaluate its right-hand side itself
+    bool strip_can_fuse(int var, int H, int r0, int r1, int ncols, int shape) const {
+        if (var == VAR_T || r1 <= r0) return false;
+        return strip_shape_for(var, H, r0, r1, ncols, shape) != SHAPE_LARGE;
+    }
+    // one launch of the register-resident Newton solve chain (tedd_strip.hpp)
+    // shape: SHAPE_LARGE / SHAPE_SMALL / SHAPE_MID, or -1 = by mesh size and system: small tiles when
+    // the large ones would leave compute units without work (fewer than 2 tiles per unit); otherwise
+    // large tiles for T and 48-row tiles for cl and cd (tedd_strip.hpp, StripShape).  A shape whose
+    // tile the depth H does not fit falls back to the large one.
+    template <int VAR, int REACT, bool LAST>
+    void solve_strip(int fam, StripArgs A, int ncols, int shape = -1) {
+        if (A.r1 <= A.r0) return;
+        if (A.H < 0 || A.H > 16 || A.nsweeps < 0 || A.nsweeps > A.H) throw std::runtime_error("bad strip-solve depth");
+        const bool fused = (A.Y != nullptr);
+        if (!fused && (A.b_in == nullptr || (A.d_in == nullptr && A.u_prev == nullptr)))
+            throw std::runtime_error("strip solve needs rhs/diag and a starting iterate");
+        if (fused && (A.fv == nullptr || A.a.Tn == nullptr || (VAR == VAR_CD && A.a.cln == nullptr)))
+            throw std::runtime_error("fused strip solve needs Y, the forcing array and the new T (and cl)");
+        Scope sc(this, fam);
+        const int TIC = kSTile - 2 * strip_col_halo(A.H + (fused ? 1 : 0));  // (as the kernel computes it)
+        A.tiles_x = (ncols + TIC - 1) / TIC;
+        shape = strip_shape_for(VAR, A.H, A.r0, A.r1, ncols, shape);
+        const int TIR = strip_tile_rows(shape) - 2 * A.H;
+        const long long nt = (long long)A.tiles_x * ((A.r1 - A.r0 + TIR - 1) / TIR);
         if (nt > 0x7fffffffLL) throw std::runtime_error("mesh too large for the tile index");
         const bool warm = (A.u_prev != nullptr);
         if (warm && A.stats_first == nullptr) throw std::runtime_error("warm strip solve needs a record slot");
-        auto launch = [&](auto shape_c, auto warm_c) {
+        auto launch = [&](auto shape_c, auto warm_c, auto fused_c, auto xface_c) {
             constexpr int SH = decltype(shape_c)::value;
             constexpr bool WM = decltype(warm_c)::value;
-            hipLaunchKernelGGL((k_solve_strip<VAR, REACT, LAST, SH, WM>), dim3((unsigned)nt),
+            constexpr bool FU = decltype(fused_c)::value;
+            constexpr bool XF = decltype(xface_c)::value;
+            hipLaunchKernelGGL((k_solve_strip<VAR, REACT, LAST, SH, WM, FU, XF>), dim3((unsigned)nt),
                                dim3(kSTile, StripShape<VAR, SH>::W), 0, stream, A);
         };
-        auto by_warm = [&](auto shape_c) {
+        auto by_warm = [&](auto shape_c, auto fused_c, auto xface_c) {
             if (warm)
-                launch(shape_c, std::true_type{});
+                launch(shape_c, std::true_type{}, fused_c, xface_c);
             else
-                launch(shape_c, std::false_type{});
+                launch(shape_c, std::false_type{}, fused_c, xface_c);
+        };
+        auto by_fused = [&](auto shape_c) {
+            constexpr int SH = decltype(shape_c)::value;
+            if constexpr (LAST && VAR != VAR_T && SH != SHAPE_LARGE) {
+                if (fused) {
+                    by_warm(shape_c, std::true_type{}, std::false_type{});
+                    return;
+                }
+                if (A.xface) {  // (test hook: the launch a fused one must equal bit for bit)
+                    by_warm(shape_c, std::false_type{}, std::true_type{});
+                    return;
+                }
+            }
+            if (fused) throw std::runtime_error("this strip launch cannot evaluate its right-hand side");
+            by_warm(shape_c, std::false_type{}, std::false_type{});
         };
         if (shape == SHAPE_SMALL)
-            by_warm(std::integral_constant<int, SHAPE_SMALL>{});
+            by_fused(std::integral_constant<int, SHAPE_SMALL>{});
         else if (shape == SHAPE_MID)
-            by_warm(std::integral_constant<int, SHAPE_MID>{});
+            by_fused(std::integral_constant<int, SHAPE_MID>{});
         else
-            by_warm(std::integral_constant<int, SHAPE_LARGE>{});
+            by_fused(std::integral_constant<int, SHAPE_LARGE>{});
         TEDD_HIP(hipGetLastError());
     }
     template <int CASE, int REACT>

@@ -41,9 +41,11 @@ struct ModelC {
 // at least as accurate as the library routine, at a sixth of its cost; almost every exponential
 // on this path has such an argument (phi_l cp, phi_d cp, phi_T/T, the MMS time integrals).  The
 // branch is wave-uniform in practice, so the library path is skipped entirely when no lane needs it.
+TEDD_HD double tedd_exp_series(double x) {
+    return 1.0 + x * (1.0 + x * (0.5 + x * (1.0 / 6.0 + x * (1.0 / 24.0 + x * (1.0 / 120.0)))));
+}
 TEDD_HD double tedd_exp(double x) {
-    if (fabs(x) < 0x1p-10)
-        return 1.0 + x * (1.0 + x * (0.5 + x * (1.0 / 6.0 + x * (1.0 / 24.0 + x * (1.0 / 120.0)))));
+    if (fabs(x) < 0x1p-10) return tedd_exp_series(x);
     return exp(x);
 }
 
@@ -102,6 +104,14 @@ TEDD_HD double law_dDd_dT(const ModelC& m, double c, double T) {
 
 // Dd and dDd/dT at once: one reciprocal and one exponential instead of three divisions and two
 // exponentials (the right-hand side of the cd system needs both on every face)
+// (law_Dd_pair's Dd alone, by the same operations)
+TEDD_HD double law_Dd_p(const ModelC& m, double c, double T) {
+    const double Te = T + m.T_shift;
+    const double rTe = tedd_div(1.0, (Te != 0.0) ? Te : 1.0);
+    const double x = m.phi_T * rTe;
+    const double E = m.Dd_max * tedd_exp(-m.phi_d * c - x);
+    return (Te != 0.0) ? E : 0.0;
+}
 TEDD_HD void law_Dd_pair(const ModelC& m, double c, double T, double& D, double& dT) {
     const double Te = T + m.T_shift;
     const double rTe = tedd_div(1.0, (Te != 0.0) ? Te : 1.0);

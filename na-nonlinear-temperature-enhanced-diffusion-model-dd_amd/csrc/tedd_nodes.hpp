@@ -354,35 +354,43 @@ TEDD_HD void newton_row(const ModelC& m, const GridDev& g, const NewtonIn& a, in
 // + dt (dFcd/dcl)(cln - cl).
 // D_out (optional): receives the face diffusivities the right-hand side evaluated (cl, cd).
 // From values (cl and cd systems): fv forcing value, Y = Y_v, u the lagged unknown with its neighbours, Tn the
-// new T with its neighbours (cl: only e, w are used), w_ok / e_ok: 0 where node (i-1,j) / (i+1,j) is a boundary node.
+// new T with its neighbours (cl: only e, w are used), w_ok / e_ok: 0 where node (i-1,j) / (i+1,j) is a boundary
+// node.  D: the face diffusivities (Dl for cl, Dd for cd); dD: dDd/dT on the faces (cd only).
 template <int VAR, int REACT>
-TEDD_HD double newton_rhs_vals(const ModelC& m, const Geo& ge, double dt, double fv, double Y, double w_ok, double e_ok,
-                               const St5& cp, const St5& T, const St5& u, const St5& Tn, double clc, double csc,
-                               double clnc, Face4* D_out) {
+TEDD_HD double newton_rhs_from_faces(const ModelC& m, const Geo& ge, double dt, double fv, double Y, double w_ok,
+                                     double e_ok, const Face4& D, const Face4& dD, double cp_c, const St5& T,
+                                     const St5& u, const St5& Tn, double clc, double csc, double clnc) {
     double r;
     if (VAR == VAR_CL) {
         const St5& cl = u;
-        const Face4 Dl = faces_Dl(m, cp);
-        if (D_out) *D_out = Dl;
-        const double F = fv + rhs_cl(m, ge, Dl, T, cl, cp.c);
+        const double F = fv + rhs_cl(m, ge, D, T, cl, cp_c);
         // coupling  dt * (dFcl/dT) (Tn - To), boundary entries of (Tn - To) dropped
         const Coef5 k = jac_T_Fcl(m, ge, cl, w_ok, e_ok);
         const double ww = Tn.w - T.w, we = Tn.e - T.e;
         r = Y - 2.0 * cl.c + dt * F + dt * (k.e * we + k.w * ww);
     } else {
         const St5& cd = u;
-        Face4 Dd, dDd;
-        faces_Dd_pair(m, cp, T, Dd, dDd);
-        if (D_out) *D_out = Dd;
-        const double F = fv + rhs_cd_diffusion(ge, Dd, cd) + reaction<REACT>(m, clc, cd.c, csc);
+        const double F = fv + rhs_cd_diffusion(ge, D, cd) + reaction<REACT>(m, clc, cd.c, csc);
         // coupling with (Tn - To) keeps the boundary entries of the increment
-        const Coef5 k = jac_T_Fcd(ge, dDd, cd);
+        const Coef5 k = jac_T_Fcd(ge, dD, cd);
         const double JTw = k.c * (Tn.c - T.c) + k.e * (Tn.e - T.e) + k.w * (Tn.w - T.w) + k.n * (Tn.n - T.n) +
                            k.s * (Tn.s - T.s);
         const double Jclw = jac_cl_Fcd_diag<REACT>(m, cd.c, csc) * (clnc - clc);
         r = Y - 2.0 * cd.c + dt * F + dt * JTw + dt * Jclw;
     }
     return r;
+}
+template <int VAR, int REACT>
+TEDD_HD double newton_rhs_vals(const ModelC& m, const Geo& ge, double dt, double fv, double Y, double w_ok, double e_ok,
+                               const St5& cp, const St5& T, const St5& u, const St5& Tn, double clc, double csc,
+                               double clnc, Face4* D_out) {
+    Face4 D, dD{};
+    if (VAR == VAR_CL)
+        D = faces_Dl(m, cp);
+    else
+        faces_Dd_pair(m, cp, T, D, dD);
+    if (D_out) *D_out = D;
+    return newton_rhs_from_faces<VAR, REACT>(m, ge, dt, fv, Y, w_ok, e_ok, D, dD, cp.c, T, u, Tn, clc, csc, clnc);
 }
 template <int VAR, int CASE, int REACT>
 TEDD_HD double newton_rhs_value(const GridDev& g, const ModelC& m, const MmsTabs& tb, const ForcingSrc& f1,
@@ -494,6 +502,14 @@ struct StripArgs {
     const double* u_prev = nullptr;
     double gscale = 0.0;
     unsigned long long* stats_first = nullptr;
+    // fused right-hand side (single-launch chains of the cl and cd systems): the launch computes
+    // b = rhs/diag itself from Y_v, the forcing array fv of the new time level and the fields in `a`
+    // (b_in, d_in unused)
+    const double* Y = nullptr;
+    const double* fv = nullptr;
+    // test hook (single-launch cl / cd chains that read b from an array): build the matrix rows from face
+    // values evaluated as a fused launch evaluates them, so that the two can be compared bit for bit
+    int xface = 0;
 };
 
 // Convergence record of the Newton solves of one step (device memory, `red`):

@@ -55,6 +55,8 @@ struct StripShape {
     static constexpr int TR = R * W;                            // tile height (nodes), halo included
     // waves per SIMD the register budget is set for
     static constexpr int OCC = (SHAPE != SHAPE_LARGE) ? 6 : (VAR == VAR_T) ? 4 : 2;
+    // ... with the right-hand side fused in (more live columns during the set-up)
+    static constexpr int OCC_FUSED = (SHAPE == SHAPE_MID) ? 3 : (VAR == VAR_CD) ? 2 : 3;
 };
 __host__ __device__ inline int strip_tile_rows(int shape) { return shape == SHAPE_SMALL ? 32 : shape == SHAPE_MID ? 48 : 64; }
 
@@ -89,18 +91,32 @@ __device__ __forceinline__ double lane_above(double v) {
 }
 // WARM: first launch of a warm-started chain (StripArgs::u_prev, gscale, stats_first); a separate
 // instantiation so that the launches from zero iterates carry none of its registers and branches.
-template <int VAR, int REACT, bool LAST, int SHAPE, bool WARM = false>
-__global__ void __launch_bounds__((64 * StripShape<VAR, SHAPE>::W)) __attribute__((amdgpu_waves_per_eu((StripShape<VAR, SHAPE>::OCC))))
+// FUSED (cl and cd systems, the only launch of a chain, 4-row strips): the launch evaluates the right-hand
+// side of the Newton system itself -- b = rhs/diag by the arithmetic of NewtonRhsFn, from the column
+// segments of cp*, the lagged T and unknown and the new T that the thread holds anyway (row neighbours in
+// registers, column neighbours by lane shifts) -- instead of reading b from an array a launch of its own
+// wrote: five (cl) / seven (cd) array passes and a launch fewer per solve.
+// XFACE: the matrix rows are built from face diffusivities evaluated exactly as the right-hand-side kernel
+// evaluates them (always so with FUSED, which shares them between right-hand side and rows).  Without it the
+// cl rows use Dl at a face = Dl_max e_a e_b with one exponential e = exp(-phi_l c / 2) per node, and the cd
+// rows law_Dd: cheaper, equal to rounding, and what the launches that read b from an array use; the exact
+// variant of those launches exists so that a fused launch can be checked against them bit for bit.
+template <int VAR, int REACT, bool LAST, int SHAPE, bool WARM = false, bool FUSED = false, bool XFACE = false>
+__global__ void __launch_bounds__((64 * StripShape<VAR, SHAPE>::W))
+__attribute__((amdgpu_waves_per_eu((FUSED ? StripShape<VAR, SHAPE>::OCC_FUSED : StripShape<VAR, SHAPE>::OCC))))
 k_solve_strip(const StripArgs A) {
     constexpr int R = StripShape<VAR, SHAPE>::R, W = StripShape<VAR, SHAPE>::W, TR = StripShape<VAR, SHAPE>::TR;
     constexpr bool LEAN = (VAR == VAR_T);
+    static_assert(!FUSED || (LAST && !LEAN && R == 4), "fused right-hand side: last launch of a cl/cd chain, 4-row strips");
     __shared__ double seam[2][W][2][kSTile];  // [parity][wave][first/last row of the strip][lane]
     __shared__ double2 rowc[LEAN ? TR : 1];  // lean rows: (dt J_e, dt J_w) of each tile row
     const int lane = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const GridDev& g = A.g;
     const ModelC& m = A.m;
-    const int H = A.H, HC = strip_col_halo(H);
+    // (fused right-hand side: b at the two end lanes of the wave lacks a column neighbour, so the column
+    // halo is one deeper than the sweeps alone need)
+    const int H = A.H, HC = strip_col_halo(H + (FUSED ? 1 : 0));
     const int TIR = TR - 2 * H, TIC = kSTile - 2 * HC;
 
     // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2); give each XCD
@@ -121,14 +137,23 @@ k_solve_strip(const StripArgs A) {
     double cpv[R + 2];  // cp at rows row0-1 .. row0+R
     double Tv[R + 2];   // lagged T at the same rows (cl, cd systems)
     double clv[R], csv[R];
+    // fused right-hand side: the lagged unknown and the new T at rows row0-1 .. row0+R, Y_v, the forcing
+    // array and (cd) the new cl at the thread's own rows
+    double uov[FUSED ? R + 2 : 1], Tnv[FUSED ? R + 2 : 1], Yv[FUSED ? R : 1], fvv[FUSED ? R : 1];
+    double clnv[(FUSED && VAR == VAR_CD) ? R : 1];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const size_t c = (size_t)min(max(row0 + k, 0), rmax) * g.ld + jc;
-        b[k] = A.b_in[c];
+        if (!FUSED) b[k] = A.b_in[c];
         if (LEAN && !WARM) d[k] = A.d_in[c];  // (the same line as b[k] in the first launch of a cold chain)
         if (VAR == VAR_CD) {
             clv[k] = A.a.clo[c];
             csv[k] = A.a.cs1[c];
+        }
+        if (FUSED) {
+            Yv[k] = A.Y[c];
+            fvv[k] = A.fv[c];
+            if (VAR == VAR_CD) clnv[k] = A.a.cln[c];
         }
     }
 #pragma unroll
@@ -137,23 +162,50 @@ k_solve_strip(const StripArgs A) {
         const size_t c = (size_t)min(max(row0 + k - 1, 0), rmax) * g.ld + jc;
         cpv[k] = A.a.cp1[c];
         if (!LEAN) Tv[k] = A.a.To[c];
+        if (FUSED) {
+            uov[k] = (VAR == VAR_CL ? A.a.clo : A.a.cdo)[c];
+            Tnv[k] = A.a.Tn[c];
+        }
     }
     const double rks = g.rk[jc], rkn = g.rk[min(jc + 1, g.ncols - 1)], rkm = g.rkm[jc];
 
     // ---- matrix rows
-    // full rows (cl, cd): ce..cs scaled by 1/diag.  Every face coefficient is evaluated once: the
-    // x face between rows k-1 and k is carried from one node to the next, the y face comes from
-    // the lane below.
+    // full rows (cl, cd): ce..cs scaled by 1/diag.  Every face coefficient is evaluated once, by the
+    // arithmetic of faces_Dl / faces_Dd_pair (the right-hand-side kernel's): the R+1 x faces of the
+    // thread's column segment and its R y faces towards column j+1; the y face towards j-1 is the lane
+    // below's.
     // lean rows (T): inv = 1/diag per node, the e/w off-diagonals per row (LDS), on/os per lane.
     double ce[LEAN ? 1 : R], cw[LEAN ? 1 : R], cn[LEAN ? 1 : R], cs[LEAN ? 1 : R];
     double inv[LEAN ? R : 1];
     double on = 0.0, os = 0.0;
-    // cl: Dl at a face = Dl_max exp(-phi_l (c_a + c_b)/2) = Dl_max e_a e_b with e = exp(-phi_l c/2)
-    // per node -- one exponential per node instead of one per face
-    double ev[VAR == VAR_CL ? R + 2 : 1];
-    if (VAR == VAR_CL) {
-        // one wave-uniform choice between the short series and the library routine for the whole strip
-        // (tedd_exp's per-value branch would split the set-up into dozens of basic blocks)
+    constexpr bool EXACT = FUSED || XFACE;
+    constexpr int NF = LEAN ? 1 : 2 * R + 1;       // [0..R] x faces (between rows k-1 and k), [R+1..2R] y faces of row k
+    constexpr bool WANT_DT = FUSED && VAR == VAR_CD;  // dDd/dT on the faces (coupling with the new T)
+    double Df[NF], dDf[WANT_DT ? NF : 1];
+    if (VAR == VAR_CL && EXACT) {
+        // Dl_max exp(-phi_l c) at the face means.  One wave-uniform choice between the short series and the
+        // series with the library routine patched in where a value needs it (value by value the result is
+        // tedd_exp's; its per-value branch would split the set-up into dozens of basic blocks)
+        bool small = true;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const double cm = (f <= R) ? 0.5 * (cpv[f + 1] + cpv[f])
+                                       : 0.5 * (lane_above(cpv[f - R]) + cpv[f - R]);
+            Df[f] = -m.phi_l * cm;
+            small = small && fabs(Df[f]) < 0x1p-10;
+        }
+        const bool all_small = __all(small);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const double x = Df[f];
+            double E = tedd_exp_series(x);
+            if (!all_small) E = (fabs(x) < 0x1p-10) ? E : exp(x);
+            Df[f] = m.Dl_max * E;
+        }
+    } else if (VAR == VAR_CL) {
+        // Dl at a face = Dl_max exp(-phi_l (c_a + c_b)/2) = Dl_max e_a e_b with e = exp(-phi_l c/2) per node:
+        // one exponential per node instead of one per face (wave-uniform choice of the routine, as above)
+        double ev[R + 2];
         bool small = true;
 #pragma unroll
         for (int k = 0; k < R + 2; ++k) {
@@ -162,25 +214,37 @@ k_solve_strip(const StripArgs A) {
         }
         if (__all(small)) {
 #pragma unroll
-            for (int k = 0; k < R + 2; ++k) {
-                const double x = ev[k];
-                ev[k] = 1.0 + x * (1.0 + x * (0.5 + x * (1.0 / 6.0 + x * (1.0 / 24.0 + x * (1.0 / 120.0)))));
-            }
+            for (int k = 0; k < R + 2; ++k) ev[k] = tedd_exp_series(ev[k]);
         } else {
 #pragma unroll
             for (int k = 0; k < R + 2; ++k) ev[k] = exp(ev[k]);
         }
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+            Df[f] = (f <= R) ? m.Dl_max * (ev[f + 1] * ev[f]) : m.Dl_max * (lane_above(ev[f - R]) * ev[f - R]);
+    } else if (VAR == VAR_CD) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            double cm, Tm;
+            if (f <= R) {
+                cm = 0.5 * (cpv[f + 1] + cpv[f]);
+                Tm = 0.5 * (Tv[f + 1] + Tv[f]);
+            } else {
+                cm = 0.5 * (lane_above(cpv[f - R]) + cpv[f - R]);
+                Tm = 0.5 * (lane_above(Tv[f - R]) + Tv[f - R]);
+            }
+            if (WANT_DT)
+                law_Dd_pair(m, cm, Tm, Df[f], dDf[f]);
+            else if (EXACT)
+                Df[f] = law_Dd_p(m, cm, Tm);
+            else
+                Df[f] = law_Dd(m, cm, Tm);
+        }
     }
-    auto x_face = [&](int k) {  // face between rows row0+k-1 and row0+k
-        if (VAR == VAR_CL) return m.Dl_max * (ev[k + 1] * ev[k]);
-        return law_Dd(m, 0.5 * (cpv[k + 1] + cpv[k]), 0.5 * (Tv[k + 1] + Tv[k]));
-    };
     auto is_active = [&](int li) {  // nodes the system has an unknown at
         const int i = g.i0 + li;
         return col_interior && li >= 1 && li <= g.nrows - 2 && i >= 1 && i <= g.N - 1;
     };
-    double Dw = 0.0;
-    if (!LEAN) Dw = x_face(0);
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int li = row0 + k;
@@ -196,14 +260,8 @@ k_solve_strip(const StripArgs A) {
             on = A.dt * r.n;
             os = A.dt * r.s;
         } else {
-            double Dn;
-            if (VAR == VAR_CL)
-                Dn = m.Dl_max * (lane_above(ev[k + 1]) * ev[k + 1]);
-            else
-                Dn = law_Dd(m, 0.5 * (lane_above(cpv[k + 1]) + cpv[k + 1]), 0.5 * (lane_above(Tv[k + 1]) + Tv[k + 1]));
-            const double Dee = x_face(k + 1);
-            const Face4 D{Dw, Dee, lane_below(Dn), Dn};
-            Dw = Dee;
+            const double Dn = Df[R + 1 + k];
+            const Face4 D{Df[k], Df[k + 1], lane_below(Dn), Dn};
             if (VAR == VAR_CL) {
                 St5 T;
                 T.c = 0.0; T.n = 0.0; T.s = 0.0;
@@ -216,7 +274,34 @@ k_solve_strip(const StripArgs A) {
                 r.w = r.s;
                 r.s = tmp;
             }
-            const double iv = rcp_straight(2.0 - A.dt * r.c);
+            const double diag = 2.0 - A.dt * r.c;
+            if (FUSED) {
+                // right-hand side at this node (newton_rhs_from_faces: the arithmetic of NewtonRhsFn)
+                const int i = g.i0 + li;
+                const double w_ok = (i > 1) ? 1.0 : 0.0, e_ok = (i < g.N - 1) ? 1.0 : 0.0;
+                St5 T, u, Tn;
+                T.c = Tv[k + 1]; T.e = Tv[k + 2]; T.w = Tv[k];
+                u.c = uov[k + 1]; u.e = uov[k + 2]; u.w = uov[k];
+                u.n = lane_above(uov[k + 1]);
+                u.s = lane_below(uov[k + 1]);
+                Tn.c = Tnv[k + 1]; Tn.e = Tnv[k + 2]; Tn.w = Tnv[k];
+                Face4 dD{};
+                if (VAR == VAR_CD) {
+                    T.n = lane_above(Tv[k + 1]);
+                    T.s = lane_below(Tv[k + 1]);
+                    Tn.n = lane_above(Tnv[k + 1]);
+                    Tn.s = lane_below(Tnv[k + 1]);
+                    const double dDn = dDf[WANT_DT ? R + 1 + k : 0];
+                    dD = Face4{dDf[WANT_DT ? k : 0], dDf[WANT_DT ? k + 1 : 0], lane_below(dDn), dDn};
+                } else {
+                    T.n = 0.0; T.s = 0.0; Tn.n = 0.0; Tn.s = 0.0;
+                }
+                const double rr = newton_rhs_from_faces<VAR, REACT>(
+                    m, ge, A.dt, fvv[k], Yv[k], w_ok, e_ok, D, dD, cpv[k + 1], T, u, Tn, (VAR == VAR_CD) ? clv[k] : 0.0,
+                    (VAR == VAR_CD) ? csv[k] : 0.0, (VAR == VAR_CD) ? clnv[k] : 0.0);
+                b[k] = tedd_div(rr, diag);
+            }
+            const double iv = rcp_straight(diag);
             ce[k] = active ? (A.dt * r.e) * iv : 0.0;
             cw[k] = active ? (A.dt * r.w) * iv : 0.0;
             cn[k] = active ? (A.dt * r.n) * iv : 0.0;
@@ -234,11 +319,11 @@ k_solve_strip(const StripArgs A) {
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const size_t c = (size_t)min(max(row0 + k, 0), rmax) * g.ld + jd;
-            const double v = A.gscale * (uo_[c] - A.u_prev[c]);
+            const double v = A.gscale * ((FUSED ? uov[FUSED ? k + 1 : 0] : uo_[c]) - A.u_prev[c]);
             d[k] = is_active(row0 + k) ? v : 0.0;
         }
     } else if (LEAN) {
-    } else if (A.d_in == A.b_in) {
+    } else if (FUSED || A.d_in == A.b_in) {
 #pragma unroll
         for (int k = 0; k < R; ++k) d[k] = b[k];
     } else {
@@ -371,12 +456,13 @@ k_solve_strip(const StripArgs A) {
             const int li = row0w + k;
             if (r >= H && r < TR - H && li >= A.r0 && li < A.r1 && lane_in) {
                 const size_t c = at(g, li, jw);
+                const double uold = FUSED ? uov[FUSED ? k + 1 : 0] : uo[c];
                 if (is_interior(g, li, jw)) {
-                    A.u_out[c] = uo[c] + d[k];
+                    A.u_out[c] = uold + d[k];
                     const double mag = fabs(d[k]);
                     mag_max = (mag > mag_max || mag != mag) ? mag : mag_max;
                 } else {
-                    A.u_out[c] = (VAR == VAR_T) ? 0.0 : uo[c];
+                    A.u_out[c] = (VAR == VAR_T) ? 0.0 : uold;
                 }
             }
         }

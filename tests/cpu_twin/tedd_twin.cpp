@@ -57,6 +57,11 @@ struct CpuBackend {
         }
         if (a.clear) std::memset(a.red, 0, 16 * sizeof(double));
     }
+    template <class F>
+    void nodes_with_prologue(int fam, const F& f, int r0, int r1, int ncols, const StepRecordArgs& a) {
+        step_prologue(a);
+        nodes(fam, f, r0, r1, ncols);
+    }
     void* alloc_host_visible(size_t bytes) { return std::calloc(bytes ? bytes : 1, 1); }
     void free_host_visible(void* p) { std::free(p); }
     void* device_view(void* p) { return p; }

@@ -58,3 +58,46 @@ def test_marching_launcher_on_a_slab_with_ghost_rows():
     got = _run(150, 200, _ffi.REACT_REGHCSTRIPLE, {"march": 1, "march_rows": 16}, **kw)
     for a, b in zip(ref, got):
         np.testing.assert_array_equal(a[16:-16], b[16:-16])
+
+
+# ---- the cl / cd solve that evaluates its right-hand side itself against right-hand-side launch + solve launch
+def _run_solve(N, M, react, options, steps=3, sweeps=None, consts=None):
+    x = np.linspace(0, 1, N + 1) ** 1.07
+    y = np.linspace(0, 1, M + 1) ** 0.93
+    ctx = _ffi.Context(x, y, STRESS if consts is None else consts, model_kind=2, reaction_kind=react, eta=30.0, mms_case=_ffi.MMS_PEAKS,
+                       mms_params=(1.0, 10.0))
+    for k, v in options.items():
+        ctx.set_option(k, v)
+    ctx.set_state_exact(0.0)
+    for k in range(steps):
+        ctx.step_pc(k * 2e-3, 2e-3, jacobi_sweeps=sweeps, cs_newton_iterations=3)
+    out = ctx.get_state()
+    stats = ctx.get_stats()
+    ctx.close()
+    return out, stats
+
+
+@pytest.mark.parametrize("shape", [1, 2], ids=["32-row tiles", "48-row tiles"])
+@pytest.mark.parametrize("react", [_ffi.REACT_CSTRIPLE, _ffi.REACT_REGHCSTRIPLE, _ffi.REACT_HCSTRIPLE])
+@pytest.mark.parametrize("sweeps", [(5, 4, 3), None], ids=["fixed sweeps", "library's sweeps (warm start)"])
+def test_fused_right_hand_side_is_bit_identical(shape, react, sweeps):
+    _fused_against_two_launches(shape, react, sweeps, STRESS if sweeps else MILD)
+
+
+# notebook-like constants: the library's own sweep counts then are a handful (single-launch chains, which fuse)
+MILD = [8.3144621, 1.60217662e-19, 1e-3, 1e-3, 1e-3, 1e-3, 1e-3, 1e-4, 1e-2, 1e-3, 1e-2, 1.0, 1e-4, 1e-2, 50.0, 5e-2, 300.0]
+
+
+def _fused_against_two_launches(shape, react, sweeps, consts):
+    """... against the two-launch solve whose matrix rows are built from the same face values ("exact_faces":
+    the right-hand-side kernel's arithmetic; by default the two-launch solve uses a cheaper form of the same
+    diffusivities for its rows, which moves the result by rounding only)."""
+    steps = 3 if sweeps else 7
+    ref, st0 = _run_solve(131, 200, react, {"fuse_rhs": 0, "exact_faces": 1, "strip_shape": shape}, steps, sweeps, consts)
+    got, st1 = _run_solve(131, 200, react, {"fuse_rhs": 1, "strip_shape": shape}, steps, sweeps, consts)
+    plain, _ = _run_solve(131, 200, react, {"fuse_rhs": 0, "strip_shape": shape}, steps, sweeps, consts)
+    assert st0["sweeps"] == st1["sweeps"] and st0["warm_started"] == st1["warm_started"]
+    assert sweeps is not None or max(st1["sweeps"][1:]) <= 9      # (single-launch cl / cd chains: the fused path ran)
+    for a, b, c in zip(ref, got, plain):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_allclose(c, b, rtol=0, atol=1e-15 * max(1.0, float(np.max(np.abs(b)))))
