@@ -732,7 +732,7 @@ public:
             src.tm = mms_time_fill(C.mms_case, C.model, C.mp, t);
             for (int v = 0; v < 5; ++v) src.f[v] = nullptr;
             ForcingFn<(CASE == CASE_STREAM ? CASE_POL : CASE), REACT> f{C.grid(), C.model, C.tabs(), src, o};
-            C.be.nodes(FAM_FORCING, f, 0, C.nrows, C.ncols);
+            C.be.forcing(FAM_FORCING, f, 0, C.nrows, C.ncols);
         }
     };
     void eval_forcing(double t, double* const h[5]) {
@@ -1657,10 +1657,13 @@ public:
             opt_cache_forcing = value != 0.0;
         else if (name == "fuse_forcing")
             opt_fuse_forcing = value < 0.0 ? -1 : (value != 0.0);
-        else if (name == "march" || name == "march_rows" || name == "march_occ" || name == "exact_faces") {
+        else if (name == "march" || name == "march_rows" || name == "march_occ" || name == "exact_faces" ||
+                 name == "forcing_columns") {
             if constexpr (Backend::kHasStripSolve) {
                 if (name == "exact_faces")
                     opt_exact_faces = value != 0.0;
+                else if (name == "forcing_columns")
+                    be.opt_forcing_columns = value != 0.0;
                 else if (name == "march")
                     be.opt_march = value < 0.0 ? -1 : (value != 0.0);
                 else if (name == "march_rows")

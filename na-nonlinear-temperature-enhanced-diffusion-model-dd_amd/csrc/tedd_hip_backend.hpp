@@ -202,6 +202,18 @@ __global__ void __launch_bounds__(256) k_nodes_pro(const F f, int r0, int r1, in
     const int li = r0 + blockIdx.y * kTileY + threadIdx.y;
     if (j < ncols && li < r1) f(li, j);
 }
+// Forcing arrays by threads that walk down columns: a workgroup covers 256 columns and `seg_rows` rows.  The
+// column's table entries are loaded once into registers; the row's entries have the same address in every
+// lane (scalar loads).  What a node costs is then arithmetic and five stores, and a wave's start-up
+// (arguments, table loads) is paid once per segment instead of once per node.
+template <class F, int QUAD>
+__global__ void __launch_bounds__(256) k_forcing_columns(const F f, int r0, int r1, int ncols, int seg_rows) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int ra = r0 + blockIdx.y * seg_rows, rb = min(ra + seg_rows, r1);
+    const auto ct = f.template column<QUAD>(min(j, ncols - 1));
+    if (j >= ncols) return;
+    for (int li = ra; li < rb; ++li) f.template node_in_column<QUAD>(ct, li, j);
+}
 // number of cs Newton iterations the reference keeps: k+1 for the first k with max|dx_k| < rtol min|x_k|
 __device__ __forceinline__ bool cs_stop_after(const unsigned long long* gmax, const unsigned long long* gmin, int k,
                                               double rtol) {
@@ -256,12 +268,14 @@ __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_R
             if (record) cp_out[c] = corrector_cp(a, li, j);
             cs_newton_inputs(a, li, j, y, av, x);
         }
+        double ex = active ? cs_newton_exp(x, a.m.eta) : 1.0;
         if (in_regs) {
 #pragma unroll
             for (int k = 0; k < kCsReg; ++k) {
                 if (k < keep && active) {
-                    const double dx = cs_newton_step(x, y, av, a.m.eta);
+                    const double dx = cs_newton_step(x, y, av, a.m.eta, ex);
                     x = x + dx;
+                    if (k + 1 < keep) ex = cs_newton_exp_next(ex, x, dx, a.m.eta);
                     double adx = fabs(dx), ax = fabs(x);
                     if (adx != adx) adx = INFINITY;
                     if (ax != ax) ax = 0.0;
@@ -273,8 +287,9 @@ __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_R
             for (int k = 0; k < keep; ++k) {
                 double adx = 0.0, ax = INFINITY;
                 if (active) {
-                    const double dx = cs_newton_step(x, y, av, a.m.eta);
+                    const double dx = cs_newton_step(x, y, av, a.m.eta, ex);
                     x = x + dx;
+                    if (k + 1 < keep) ex = cs_newton_exp_next(ex, x, dx, a.m.eta);
                     adx = fabs(dx);
                     ax = fabs(x);
                     if (adx != adx) adx = INFINITY;
@@ -355,6 +370,7 @@ struct HipBackend {
     // launcher's many small workgroups fill the GPU better), 0 never, 1 always
     int opt_march = -1;
     int opt_march_rows = 0;  // rows per segment (0: per functor, fewer on slabs with few rows)
+    int opt_forcing_columns = 1;  // forcing arrays by column-walking threads (0: one thread per node)
     int opt_march_occ = 0;   // waves per SIMD the marching kernels' register budget is set for (0: per functor; 2, 3, 4)
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -665,6 +681,26 @@ struct HipBackend {
         }
         dim3 block(kTileX, kTileY), grid((ncols + kTileX - 1) / kTileX, (r1 - r0 + kTileY - 1) / kTileY);
         hipLaunchKernelGGL(k_nodes<F>, grid, block, 0, stream, f, r0, r1, ncols);
+        TEDD_HIP(hipGetLastError());
+    }
+    // the five forcing arrays of a closed-form case (F: ForcingFn)
+    template <class F>
+    void forcing(int fam, const F& f, int r0, int r1, int ncols) {
+        check_range(r0, r1, ncols);
+        if (r1 == r0) return;
+        const int tiles_x = (ncols + 255) / 256;
+        int seg = 32;
+        while (seg > 1 && (long long)tiles_x * ((r1 - r0 + seg - 1) / seg) < 16LL * num_cus) seg /= 2;
+        const int tiles_y = (r1 - r0 + seg - 1) / seg;
+        if (opt_forcing_columns == 0 || seg < 4 || tiles_y > 65535) {  // small slab: one thread per node fills the chip better
+            nodes(fam, f, r0, r1, ncols);
+            return;
+        }
+        Scope sc(this, fam);
+        if (f.quad_mode() == 1)
+            hipLaunchKernelGGL((k_forcing_columns<F, 1>), dim3(tiles_x, tiles_y), dim3(256), 0, stream, f, r0, r1, ncols, seg);
+        else
+            hipLaunchKernelGGL((k_forcing_columns<F, 2>), dim3(tiles_x, tiles_y), dim3(256), 0, stream, f, r0, r1, ncols, seg);
         TEDD_HIP(hipGetLastError());
     }
     template <class F>

@@ -275,11 +275,13 @@ struct MmsPt {
 };
 // Case-specific scalars that depend on time only; filled on the host per time level.
 struct MmsTime {
-    double s[12];
+    double s[20];
 };
 // 1-D tables of the basis functions each case is built from, at the nodes (bx: [nb][nrows],
 // by: [nb][ld]) and at the 3 Gauss abscissae of each node's cell (bxq: [nbq][3][nrows],
-// byq: [nbq][3][ld]).  Rows are local (slab) rows.
+// byq: [nbq][3][ld]).  Rows are local (slab) rows.  Behind the nbq*3 quadrature rows of bxq / byq stand
+// mms_num_moments(case) rows of Gauss-weighted moments of the first quadrature basis function over the
+// node's cell:  moment n = sum_a w_a f(p_a)^(n+2).
 struct MmsTabs {
     const double* bx;
     const double* by;
@@ -295,6 +297,52 @@ TEDD_HD double tab_yq(const MmsTabs& t, int k, int b, int j) { return t.byq[((si
 
 constexpr int mms_num_basis(int c) { return c == CASE_POL ? 2 : c == CASE_EXPSIN ? 2 : c == CASE_PEAKS ? 3 : c == CASE_NFS ? 15 : 0; }
 constexpr int mms_num_qbasis(int c) { return c == CASE_POL ? 1 : c == CASE_EXPSIN ? 1 : c == CASE_PEAKS ? 2 : c == CASE_NFS ? 3 : 0; }
+constexpr int kExpSinMoments = 6;
+constexpr int mms_num_moments(int c) { return c == CASE_EXPSIN ? kExpSinMoments : 0; }
+TEDD_HD double tab_xmom(const MmsTabs& t, int nbq, int n, int li) { return t.bxq[((size_t)nbq * 3 + n) * t.nrows + li]; }
+TEDD_HD double tab_ymom(const MmsTabs& t, int nbq, int n, int j) { return t.byq[((size_t)nbq * 3 + n) * t.ld + j]; }
+
+// The same tables for a thread that walks down ONE column: the column's entries of the y tables are held
+// in registers (loaded once), the row's entries still come from the x tables (the same address in every
+// lane of a wave that covers one row: scalar loads).  The index arguments k, a, b, n are compile-time
+// constants wherever the evaluation uses them, so y[], yq[], ym[] stay in registers.
+template <int CASE>
+struct MmsColTabs {
+    static constexpr int NB = mms_num_basis(CASE), NBQ = mms_num_qbasis(CASE), NM = mms_num_moments(CASE);
+    const double* bx;
+    const double* bxq;
+    int nrows;
+    double y[NB > 0 ? NB : 1];
+    double yq[NBQ > 0 ? NBQ * 3 : 1];
+    double ym[NM > 0 ? NM : 1];
+};
+// QUAD: 1 the moment rows only, 2 the quadrature rows only, 0 both
+template <int CASE, int QUAD>
+TEDD_HD MmsColTabs<CASE> mms_col_tabs(const MmsTabs& t, int j) {
+    MmsColTabs<CASE> c;
+    c.bx = t.bx;
+    c.bxq = t.bxq;
+    c.nrows = t.nrows;
+#pragma unroll
+    for (int k = 0; k < MmsColTabs<CASE>::NB; ++k) c.y[k] = tab_y(t, k, j);
+#pragma unroll
+    for (int k = 0; k < MmsColTabs<CASE>::NBQ * 3; ++k) c.yq[k] = (QUAD != 1) ? tab_yq(t, k / 3, k % 3, j) : 0.0;
+#pragma unroll
+    for (int n = 0; n < MmsColTabs<CASE>::NM; ++n) c.ym[n] = (QUAD != 2) ? tab_ymom(t, MmsColTabs<CASE>::NBQ, n, j) : 0.0;
+    return c;
+}
+template <int CASE>
+TEDD_HD double tab_x(const MmsColTabs<CASE>& t, int k, int li) { return t.bx[(size_t)k * t.nrows + li]; }
+template <int CASE>
+TEDD_HD double tab_y(const MmsColTabs<CASE>& t, int k, int) { return t.y[k]; }
+template <int CASE>
+TEDD_HD double tab_xq(const MmsColTabs<CASE>& t, int k, int a, int li) { return t.bxq[((size_t)k * 3 + a) * t.nrows + li]; }
+template <int CASE>
+TEDD_HD double tab_yq(const MmsColTabs<CASE>& t, int k, int b, int) { return t.yq[k * 3 + b]; }
+template <int CASE>
+TEDD_HD double tab_xmom(const MmsColTabs<CASE>& t, int nbq, int n, int li) { return t.bxq[((size_t)nbq * 3 + n) * t.nrows + li]; }
+template <int CASE>
+TEDD_HD double tab_ymom(const MmsColTabs<CASE>& t, int, int n, int) { return t.ym[n]; }
 
 TEDD_HD void mms_set_all(MmsPt& p, double u, double ut, double ux, double uy, double lap) {
     p.cp = p.T = p.cl = p.cd = p.cs = u;
@@ -306,11 +354,12 @@ TEDD_HD void mms_set_all(MmsPt& p, double u, double ut, double ux, double uy, do
 
 // ExpSin pieces shared by node and quadrature evaluation.  tm.s: 0 e^{-at}, 1 e^{-t}, 2 a,
 // 3 beta, 4 beta', 5 -K1 t, 6 q0, 7 q1, 8 q2  with  cp = W exp(-K1 t + beta W),
-// cs = r_sp W exp(q0 + q1 W + q2 W^2).
+// cs = r_sp W exp(q0 + q1 W + q2 W^2);  9: 1 if the cell average of the cp-forcing is taken from the
+// moment tables, 10: its factor  e^{-K1 t} (beta' - K1 e^{-t} + K2 e^{-at}) / 4,  11..16: beta^n / n!.
 TEDD_HD double expsin_cp(const MmsTime& tm, double W) { return W * tedd_exp(tm.s[5] + tm.s[3] * W); }
 
-template <int CASE>
-TEDD_HD MmsPt mms_node(const ModelC& m, const MmsTime& tm, const MmsTabs& tb, int li, int j) {
+template <int CASE, class TB>
+TEDD_HD MmsPt mms_node(const ModelC& m, const MmsTime& tm, const TB& tb, int li, int j) {
     MmsPt p;
     if (CASE == CASE_POL) {  // u = X(x) X(y)/(1+t), X = x(1-x); basis 0: X, 1: X'
         const double fx = tab_x(tb, 0, li), dfx = tab_x(tb, 1, li);
@@ -370,8 +419,8 @@ TEDD_HD MmsPt mms_node(const ModelC& m, const MmsTime& tm, const MmsTabs& tb, in
 
 // Pointwise cp-forcing  d_t cp + cp (K1 (1+cl) + K2 T)  of the exact solution at the Gauss point
 // (a,b) of node (li,j)'s cell  (prob1base.py:2313-2323).
-template <int CASE>
-TEDD_HD double mms_fcp_quad(const ModelC& m, const MmsTime& tm, const MmsTabs& tb, int li, int a, int j, int b) {
+template <int CASE, class TB>
+TEDD_HD double mms_fcp_quad(const ModelC& m, const MmsTime& tm, const TB& tb, int li, int a, int j, int b) {
     double cp, cp_t, cl, T;
     if (CASE == CASE_POL) {
         const double ff = tab_xq(tb, 0, a, li) * tab_yq(tb, 0, b, j);
@@ -400,10 +449,24 @@ TEDD_HD double mms_fcp_quad(const ModelC& m, const MmsTime& tm, const MmsTabs& t
 }
 
 // 3x3 Gauss-Legendre cell average of the pointwise cp-forcing (prob1base.py:493-598).
-template <int CASE>
-TEDD_HD double mms_fcp_cellavg(const ModelC& m, const MmsTime& tm, const MmsTabs& tb, int li, int j) {
+// QUAD (ExpSin): 0 the time level says which evaluation applies (tm.s[9]); 1 / 2: the caller has looked,
+// and only the moment / only the nine-point evaluation is compiled in.
+template <int CASE, int QUAD = 0, class TB = MmsTabs>
+TEDD_HD double mms_fcp_cellavg(const ModelC& m, const MmsTime& tm, const TB& tb, int li, int j) {
     const double w[3] = {5.0 / 9.0, 8.0 / 9.0, 5.0 / 9.0};
     double acc = 0.0;
+    if (CASE == CASE_EXPSIN && QUAD != 2 && (QUAD == 1 || tm.s[9] != 0.0)) {
+        // With W = sin(pi x) sin(pi y) the pointwise forcing is  cp_t + cp (K1 (1+cl) + K2 T)
+        //   = W^2 e^{-K1 t} e^{beta W} (beta' - K1 e^{-t} + K2 e^{-at}),
+        // and for |beta| < 2^-10 (the host's test behind s[9]; |W| <= 1) the six-term series of e^{beta W}
+        // is exact to rounding.  The 3x3 Gauss sum of W^(n+2) = X^(n+2) Y^(n+2) is the product of two
+        // per-axis moments, so the cell average is six products of table entries instead of nine
+        // exponentials.
+        constexpr int nbq = mms_num_qbasis(CASE_EXPSIN);
+#pragma unroll
+        for (int n = kExpSinMoments - 1; n >= 0; --n) acc += tm.s[11 + n] * (tab_xmom(tb, nbq, n, li) * tab_ymom(tb, nbq, n, j));
+        return tm.s[10] * acc;
+    }
     if (CASE == CASE_EXPSIN) {
         // The nine exponentials of the exact cp in one block: the short series of tedd_exp for all of
         // them, and the library routine only if some lane of the wave has an argument outside the

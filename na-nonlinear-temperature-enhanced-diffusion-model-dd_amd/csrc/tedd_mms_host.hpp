@@ -77,11 +77,12 @@ inline void mms_qbasis_at(int mms_case, const MmsParams& mp, double x, double* o
 // entry 0; count: entries to fill; stride: table row stride (>= count).
 inline void build_axis_tables(int mms_case, const MmsParams& mp, const std::vector<double>& coords, int first,
                               int count, int stride, std::vector<double>& nodal, std::vector<double>& quad) {
-    const int nb = mms_num_basis(mms_case), nbq = mms_num_qbasis(mms_case);
+    const int nb = mms_num_basis(mms_case), nbq = mms_num_qbasis(mms_case), nmom = mms_num_moments(mms_case);
     const int n = (int)coords.size() - 1;
     nodal.assign((size_t)nb * stride, 0.0);
-    quad.assign((size_t)nbq * 3 * stride, 0.0);
+    quad.assign((size_t)(nbq * 3 + nmom) * stride, 0.0);
     const double gl[3] = {-std::sqrt(3.0 / 5.0), 0.0, std::sqrt(3.0 / 5.0)};
+    const double gw[3] = {5.0 / 9.0, 8.0 / 9.0, 5.0 / 9.0};
     double tmp[16];
     for (int l = 0; l < count; ++l) {
         const int i = first + l;
@@ -95,6 +96,11 @@ inline void build_axis_tables(int mms_case, const MmsParams& mp, const std::vect
                 const double p = base + (gl[a] + 1.0) * 0.5 * width;
                 mms_qbasis_at(mms_case, mp, p, tmp);
                 for (int k = 0; k < nbq; ++k) quad[((size_t)k * 3 + a) * stride + l] = tmp[k];
+                double pw = tmp[0];  // moment m: sum_a w_a f(p_a)^(m+2)
+                for (int mo = 0; mo < nmom; ++mo) {
+                    pw *= tmp[0];
+                    quad[((size_t)nbq * 3 + mo) * stride + l] += gw[a] * pw;
+                }
             }
         }
     }
@@ -127,6 +133,11 @@ inline MmsTime mms_time_fill(int mms_case, const ModelC& m, const MmsParams& mp,
             tm.s[6] = -m.Kd * m.Sd * t;                 // q0
             tm.s[7] = -m.Kd * (m.Sd + 1.0) * em11;      // q1
             tm.s[8] = 0.5 * m.Kd * em12;                // q2
+            // cell-averaged cp-forcing from the moment tables while the series of e^{beta W} is exact
+            tm.s[9] = (std::fabs(tm.s[3]) < 0x1p-10) ? 1.0 : 0.0;
+            tm.s[10] = 0.25 * std::exp(tm.s[5]) * (tm.s[4] - m.K1 * e1 + m.K2 * ea);
+            tm.s[11] = 1.0;
+            for (int k = 1; k < kExpSinMoments; ++k) tm.s[11 + k] = tm.s[10 + k] * tm.s[3] / k;
             break;
         }
         default:

@@ -58,8 +58,8 @@ struct Forcing5 {
 };
 
 // All five forcing values at a node.  Unused members are dead-code-eliminated after inlining.
-template <int CASE, int REACT>
-TEDD_HD Forcing5 node_forcing(const ModelC& m, const MmsTabs& tb, const ForcingSrc& src, const GridDev& g,
+template <int CASE, int REACT, int QUAD = 0, class TB = MmsTabs>
+TEDD_HD Forcing5 node_forcing(const ModelC& m, const TB& tb, const ForcingSrc& src, const GridDev& g,
                               int li, int j, bool interior, bool want_fcp) {
     Forcing5 r;
     if (CASE == CASE_STREAM) {
@@ -76,7 +76,7 @@ TEDD_HD Forcing5 node_forcing(const ModelC& m, const MmsTabs& tb, const ForcingS
         const double gain = reaction_gain<REACT>(m, p.cs);
         r.fcd = mms_fcd_gain(m, p, gain);
         r.fcs = mms_fcs_gain(m, p, gain);
-        r.fcp = (interior && want_fcp) ? mms_fcp_cellavg<CASE>(m, src.tm, tb, li, j) : 0.0;
+        r.fcp = (interior && want_fcp) ? mms_fcp_cellavg<CASE, QUAD>(m, src.tm, tb, li, j) : 0.0;
     }
     return r;
 }
@@ -703,12 +703,24 @@ TEDD_HD void cs_newton_inputs(const CorrectIn<CASE, REACT>& a, int li, int j, do
     av = a.dt * m.Kd * (m.Sd - a.cd1[c]) * (a.cl1[c] + 1.0);
     x0 = a.cs0[c];
 }
-// one Newton update; returns dx
-TEDD_HD double cs_newton_step(double x, double y, double av, double eta) {
-    const double ex = exp(-eta * x);
+// one Newton update; returns dx.  ex = e^{-eta x}
+TEDD_HD double cs_newton_step(double x, double y, double av, double eta, double ex) {
     const double f = 2.0 * x + (2.0 * x - y) * ex - y + av;
     const double J = 2.0 + 2.0 * ex - eta * (2.0 * x - y) * ex;
     return tedd_div(-f, J);
+}
+TEDD_HD double cs_newton_exp(double x, double eta) { return exp(-eta * x); }
+// e^{-eta (x + dx)} from ex = e^{-eta x}: the iteration converges quadratically, so after its first update
+// |eta dx| is far below 2^-10 and the six-term series of e^{-eta dx} is exact to rounding; the library
+// routine serves the values beyond that (value by value the result does not depend on the other lanes).
+TEDD_HD double cs_newton_exp_next(double ex, double x_new, double dx, double eta) {
+    const double z = -eta * dx;
+    const bool small = fabs(z) < 0x1p-10;
+    const double viaser = ex * (1.0 + z * (1.0 + z * (0.5 + z * (1.0 / 6.0 + z * (1.0 / 24.0 + z * (1.0 / 120.0))))));
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__all(small)) return viaser;
+#endif
+    return small ? viaser : exp(-eta * x_new);
 }
 
 // ------------------------------------------------------------------------------------
@@ -739,7 +751,8 @@ struct ExactFn {
     }
 };
 
-// The five forcing arrays at one time (parity hook for the MMS source terms).
+// The five forcing arrays at one time level.  Per node (operator()), or for a thread that walks down a
+// column with that column's table entries in registers (column / node_in_column): the same arithmetic.
 template <int CASE, int REACT>
 struct ForcingFn {
     GridDev g;
@@ -748,13 +761,25 @@ struct ForcingFn {
     ForcingSrc f0;
     Out5 out;
     TEDD_HD void operator()(int li, int j) const {
-        const Forcing5 f = node_forcing<CASE, REACT>(m, tb, f0, g, li, j, is_interior(g, li, j), true);
+        put(li, j, node_forcing<CASE, REACT>(m, tb, f0, g, li, j, is_interior(g, li, j), true));
+    }
+    template <int QUAD>
+    TEDD_HD MmsColTabs<CASE> column(int j) const {
+        return mms_col_tabs<CASE, QUAD>(tb, j);
+    }
+    template <int QUAD>
+    TEDD_HD void node_in_column(const MmsColTabs<CASE>& ct, int li, int j) const {
+        put(li, j, node_forcing<CASE, REACT, QUAD>(m, ct, f0, g, li, j, is_interior(g, li, j), true));
+    }
+    // which evaluation of the cell average the time level asks for (see mms_fcp_cellavg)
+    int quad_mode() const { return (CASE == CASE_EXPSIN) ? (f0.tm.s[9] != 0.0 ? 1 : 2) : 2; }
+    TEDD_HD void put(int li, int j, const Forcing5& f) const {
         const size_t c = at(g, li, j);
-        out.v[0][c] = f.fcp;
-        out.v[1][c] = f.fT;
-        out.v[2][c] = f.fcl;
-        out.v[3][c] = f.fcd;
-        out.v[4][c] = f.fcs;
+        put_once(out.v[0] + c, f.fcp);
+        put_once(out.v[1] + c, f.fT);
+        put_once(out.v[2] + c, f.fcl);
+        put_once(out.v[3] + c, f.fcd);
+        put_once(out.v[4] + c, f.fcs);
     }
 };
 

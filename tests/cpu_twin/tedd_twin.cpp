@@ -87,6 +87,10 @@ struct CpuBackend {
             for (int j = 0; j < ncols; ++j) f(li, j);
     }
     template <class F>
+    void forcing(int fam, const F& f, int r0, int r1, int ncols) {
+        nodes(fam, f, r0, r1, ncols);
+    }
+    template <class F>
     void nodes_max(int, const F& f, int r0, int r1, int ncols, double* out) {
         std::vector<double> rows((size_t)std::max(r1 - r0, 0) * F::NR, 0.0);
 #pragma omp parallel for schedule(static) if (wide(r0, r1, ncols))
@@ -138,18 +142,20 @@ struct CpuBackend {
         // has combined the record with that of the other slabs) the decision, and the iteration again if
         // the reference's global test stops it early (src/prob1base.py:3654-3663) -- as the device does
         const size_t n = (size_t)(r1 - r0) * ncols;
-        std::vector<double> x0(n), x(n), y(n), av(n);
+        std::vector<double> x0(n), x(n), y(n), av(n), ex(n);
         size_t q = 0;
         for (int li = r0; li < r1; ++li)
             for (int j = 0; j < ncols; ++j, ++q) cs_newton_inputs(a, li, j, y[q], av[q], x0[q]);
         auto iterate = [&](int count, double* mx, double* mn) {
             x = x0;
+            for (size_t qq = 0; qq < n; ++qq) ex[qq] = cs_newton_exp(x[qq], a.m.eta);
             for (int k = 0; k < count; ++k) {
                 double vmx = 0.0, vmn = INFINITY;
 #pragma omp parallel for schedule(static) reduction(max : vmx) reduction(min : vmn) if (n >= 32768)
                 for (long long qq = 0; qq < (long long)n; ++qq) {
-                    const double dx = cs_newton_step(x[qq], y[qq], av[qq], a.m.eta);
+                    const double dx = cs_newton_step(x[qq], y[qq], av[qq], a.m.eta, ex[qq]);
                     x[qq] += dx;
+                    if (k + 1 < count) ex[qq] = cs_newton_exp_next(ex[qq], x[qq], dx, a.m.eta);
                     double adx = std::fabs(dx), ax = std::fabs(x[qq]);
                     if (adx != adx) adx = INFINITY;
                     if (ax != ax) ax = 0.0;

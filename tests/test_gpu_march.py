@@ -101,3 +101,45 @@ def _fused_against_two_launches(shape, react, sweeps, consts):
     for a, b, c in zip(ref, got, plain):
         np.testing.assert_array_equal(a, b)
         np.testing.assert_allclose(c, b, rtol=0, atol=1e-15 * max(1.0, float(np.max(np.abs(b)))))
+
+
+# ---- forcing arrays by column-walking threads against one thread per node
+@pytest.mark.parametrize("case,params,t", [
+    (_ffi.MMS_POL, None, 0.3), (_ffi.MMS_PEAKS, (1.0, 10.0), 0.3), (_ffi.MMS_NFS, (2.1, 3.1, 2.1, 3.1, 2.1, 1.0 / np.pi), 0.3),
+    (_ffi.MMS_EXPSIN, None, 1e-3),    # cell average from the moment tables
+    (_ffi.MMS_EXPSIN, None, 0.25),    # ... from the nine quadrature points
+], ids=["pol", "peaks", "nfs", "expsin-moments", "expsin-points"])
+@pytest.mark.parametrize("react", [_ffi.REACT_CSTRIPLE, _ffi.REACT_REGHCSTRIPLE])
+def test_forcing_by_columns_is_bit_identical(case, params, t, react):
+    """A mesh large enough for the column launch (2101 x 2051 nodes: ragged in both directions), every
+    closed-form case, both evaluations of the ExpSin cell average."""
+    x = np.linspace(0, 1, 2101) ** 1.07
+    y = np.linspace(0, 1, 2051) ** 0.93
+    out = []
+    for columns in (0, 1):
+        kw = {} if params is None else {"mms_params": params}
+        ctx = _ffi.Context(x, y, STRESS, model_kind=2, reaction_kind=react, eta=30.0, mms_case=case, **kw)
+        ctx.set_option("forcing_columns", columns)
+        out.append(ctx.eval_forcing(t))
+        ctx.close()
+    for a, b in zip(*out):
+        assert np.isfinite(a).all()
+        np.testing.assert_array_equal(a, b)
+
+
+def test_expsin_cell_average_by_moments_matches_the_nine_point_sum():
+    """The two evaluations of the ExpSin cp-forcing cell average agree to rounding where both apply: the host
+    picks the moment form for |beta(t)| < 2^-10; with K1 = K2 and DT = 1/(2 pi^2) beta vanishes identically, and
+    the nine-point sum is what the NumPy restatement computes."""
+    import tedd_oracle as orc  # (tests/conftest.py puts oracle/ on the path)
+    consts = list(STRESS)
+    x = np.linspace(0, 1, 2101) ** 1.07
+    y = np.linspace(0, 1, 2051) ** 0.93
+    ctx = _ffi.Context(x, y, consts, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=30.0,
+                       mms_case=_ffi.MMS_EXPSIN)
+    got = ctx.eval_forcing(2e-3)[0]
+    ctx.close()
+    model = orc.Model(consts, kind=2)
+    mesh = orc.Mesh(x, y)
+    want = orc.forcing_arrays(orc.CaseExpSin(model), model, mesh, 2e-3, "reg", 30.0)["fcp"]
+    assert np.abs(got - want).max() < 1e-15
