@@ -45,9 +45,12 @@ NB_A = dict(R0=8.3144621, Ea=1.60217662e-19, K1=1e-3, K2=1e-3, K3=1e-3, K4=1e-3,
 
 # Distinct full-grid arrays read + written per launch of each kernel family (algorithmic traffic:
 # 8 bytes per node per array; stencil neighbours, tile halos and 1-D tables not counted).
-def arrays_per_launch(solver, cache_forcing, sweeps, hmax, fuse_forcing=1):
+def arrays_per_launch(solver, cache_forcing, sweeps, hmax, fuse_forcing=1, warm=(False, False, False), fused_rhs=False):
     """-> ({family: arrays per launch (chain families: average over the chain's launches)},
-           {chain family: {"launches_per_solve", "arrays_per_solve"}})"""
+           {chain family: {"launches_per_solve", "arrays_per_solve"}})
+    warm[k]: the solve of system k starts from the increment of the step before (its first launch also
+    reads the unknown of the step before); fused_rhs: single-launch cl / cd solves evaluate their right-hand
+    side themselves (no rhs_cl / rhs_cd launch: the solve reads what that launch would have)."""
     a = {}
     if cache_forcing:
         a["forcing"] = 5        # writes fcp (cell averages), fT, fcl, fcd, fcs of the new time level
@@ -80,6 +83,10 @@ def arrays_per_launch(solver, cache_forcing, sweeps, hmax, fuse_forcing=1):
             # every launch reads b and the coefficient fields and writes one array; launches after the
             # first also read the iterate; the last also reads the lagged unknown
             arr = sum(1 + coef[var] + (1 if l > 0 else 0) + (1 if l == L - 1 else 0) + 1 for l in range(L))
+            if warm[k]:
+                arr += 1 + (0 if L == 1 else 1)     # u_{n-1}, and the lagged unknown unless the launch reads it anyway
+            if fused_rhs and L == 1 and var != "T":
+                arr = a["rhs_" + var] - 1 + 1 + (1 if warm[k] else 0)   # the rhs launch's reads, one array written
         else:
             continue
         chains["solve_" + var] = {"launches_per_solve": L, "arrays_per_solve": arr}
@@ -442,7 +449,9 @@ def main():
     err_H = float(np.sqrt(np.sum(norms[:5])))
 
     n_nodes_local = (slab.row_hi - slab.row_lo) * (N + 1)
-    arrays, chains = arrays_per_launch(args.solver, args.cache_forcing, sweeps, args.hmax, args.fuse_forcing)
+    arrays, chains = arrays_per_launch(args.solver, args.cache_forcing, sweeps, args.hmax, args.fuse_forcing,
+                                       warm=stats["warm_started"],
+                                       fused_rhs=args.solver == "strip" and "rhs_cl" not in prof)
 
     def gbps(fam):
         per_launch_s = prof[fam]["total_ms"] / prof[fam]["launches"] * 1e-3

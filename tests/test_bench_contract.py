@@ -24,6 +24,12 @@ def test_array_passes_of_the_default_step():
     # the predictor launch makes the forcing arrays itself on small slabs: no forcing launch, 5 more writes
     fused, _ = bench.arrays_per_launch("strip", 1, sweeps, 10, 1)
     assert "forcing" not in fused and fused["predict"] == 23
+    # a warm-started T solve of 10 sweeps is one launch: b, cp*, T_n, T_{n-1} read, T_new written
+    warm, chains = bench.arrays_per_launch("strip", 1, [10, 7, 5], 10, 0, warm=(True, False, False))
+    assert chains["solve_T"] == {"launches_per_solve": 1, "arrays_per_solve": 5}
+    # small slabs: the cl / cd solves read what their right-hand-side launches would have
+    small, _ = bench.arrays_per_launch("strip", 1, [10, 5, 4], 10, 1, fused_rhs=True)
+    assert small["solve_cl"] == 7 and small["solve_cd"] == 10
 
 
 def test_sweep_counts_follow_the_contraction_bound():
@@ -31,15 +37,15 @@ def test_sweep_counts_follow_the_contraction_bound():
         assert bench.pick_sweeps(N, (1.0 / N) ** 1.5, 1e-13) == expect
 
 
-def test_committed_pmc_summary_feeds_the_traffic_figure(monkeypatch):
-    # (the mechanism, on the counter summary of the first round's kernels; bench.py itself only accepts
-    # summaries of the kernels of the present tree, PMC_PROFILE_TAG)
-    monkeypatch.setattr(bench, "PMC_PROFILE_TAG", "r01_v9")
+def test_committed_pmc_summary_feeds_the_traffic_figure():
     cfg = {"mesh_N": 16384, "solver": "strip", "sweeps_per_launch": 10, "forcing": "arrays per time level"}
     tr = bench.pmc_traffic("predict", cfg)
-    assert tr is not None and tr["source"].startswith("profiles/")
+    assert tr is not None and tr["source"].startswith("profiles/" + bench.PMC_PROFILE_TAG)
     algorithmic = 8.0 * 16385 * 16385 * 21
-    assert algorithmic < tr["bytes_per_launch"] < 1.35 * algorithmic
+    assert algorithmic < tr["bytes_per_launch"] < 1.05 * algorithmic     # every array row is read once
+    for fam, arrays in (("rhs_cl", 7), ("rhs_cd", 10), ("forcing", 5), ("cs_newton", 8)):
+        got = bench.pmc_traffic(fam, cfg)["bytes_per_launch"]
+        assert 0.99 * arrays < got / (8.0 * 16385 * 16385) < 1.05 * arrays, fam
     assert bench.pmc_traffic("predict", dict(cfg, mesh_N=123)) is None
 
 
