@@ -21,6 +21,7 @@ thread_local std::string g_create_error;
 template <class Fn>
 int guarded(tedd_ctx* c, Fn&& fn) {
     if (!c || !c->impl) return TEDD_ERR_INVALID;
+    typename TEDD_BACKEND::DeviceKeeper keep;
     try {
         c->impl->be.use_device();
         fn(*c->impl);
@@ -49,6 +50,7 @@ int tedd_create(tedd_ctx** out, const tedd_config* cfg, const double* x, const d
         return TEDD_ERR_INVALID;
     }
     *out = nullptr;
+    typename TEDD_BACKEND::DeviceKeeper keep;
     try {
         tedd_ctx* c = new tedd_ctx();
         try {
@@ -70,7 +72,9 @@ int tedd_create(tedd_ctx** out, const tedd_config* cfg, const double* x, const d
 
 void tedd_destroy(tedd_ctx* ctx) {
     if (!ctx) return;
+    typename TEDD_BACKEND::DeviceKeeper keep;
     try {
+        if (ctx->impl) ctx->impl->be.use_device();
         delete ctx->impl;
     } catch (...) {
     }
@@ -121,6 +125,7 @@ int tedd_get_state(tedd_ctx* ctx, double* cp, double* T, double* cl, double* cd,
 }
 int tedd_state_device_ptrs(tedd_ctx* ctx, void* ptrs[5]) {
     return guarded(ctx, [&](auto& C) {
+        if (!ptrs) throw tedd::InvalidError("ptrs is null");
         C.require_state();
         for (int v = 0; v < 5; ++v) ptrs[v] = C.cur[v];
     });
@@ -249,6 +254,7 @@ int tedd_profile_enable(tedd_ctx* ctx, int32_t enable) {
 int tedd_profile_get(tedd_ctx* ctx, int32_t cap, const char** names, int64_t* launches, double* total_ms) {
     int n = 0;
     const int rc = guarded(ctx, [&](auto& C) {
+        if (cap < 0 || (cap > 0 && (!names || !launches || !total_ms))) throw tedd::InvalidError("null output array");
         C.be.profile_collect();
         for (int f = 0; f < tedd::FAM_COUNT && n < cap; ++f) {
             if (C.be.fam_n[f] == 0) continue;

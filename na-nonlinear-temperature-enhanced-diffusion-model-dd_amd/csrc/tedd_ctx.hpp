@@ -176,20 +176,27 @@ public:
         ld = ((ncols + 15) / 16) * 16;
         mms_case = c.mms_case;
         react = c.reaction_kind;
-        be.init(c.device);
-        set_model(c.consts, c.model_kind, c.eta, c.mms_params);
-        build_geometry();
-        build_mms_tables();
-        d_red = (double*)be.alloc(64 * sizeof(double));
-        d_ints = (int*)be.alloc(16 * sizeof(int));
-        be.memset0(d_red, 64 * sizeof(double));
-        be.memset0(d_ints, 16 * sizeof(int));
-        h_ring = (double*)be.alloc_host_visible((size_t)kRing * 16 * sizeof(double));
-        d_ring = (double*)be.device_view(h_ring);
-        for (int k = 0; k < kRing; ++k) h_ring[16 * k] = -1.0;
         for (int v = 0; v < 5; ++v) cur[v] = nullptr;
+        // (a constructor that throws runs no destructor: what was allocated so far is released here)
+        try {
+            be.init(c.device);
+            set_model(c.consts, c.model_kind, c.eta, c.mms_params);
+            build_geometry();
+            build_mms_tables();
+            d_red = (double*)be.alloc(64 * sizeof(double));
+            d_ints = (int*)be.alloc(16 * sizeof(int));
+            be.memset0(d_red, 64 * sizeof(double));
+            be.memset0(d_ints, 16 * sizeof(int));
+            h_ring = (double*)be.alloc_host_visible((size_t)kRing * 16 * sizeof(double));
+            d_ring = (double*)be.device_view(h_ring);
+            for (int k = 0; k < kRing; ++k) h_ring[16 * k] = -1.0;
+        } catch (...) {
+            release_all();
+            throw;
+        }
     }
-    ~Ctx() {
+    ~Ctx() { release_all(); }
+    void release_all() noexcept {
         for (double* p : all_bufs) be.free(p);
         for (double*& p : slot) be.free(p);
         be.free(d_geo_rows);
@@ -211,6 +218,7 @@ public:
         be.free(d_ints);
         be.sync_quiet();  // a prologue launch may still be writing the ring
         be.free_host_visible(h_ring);
+        h_ring = nullptr;
         be.shutdown();
     }
 

@@ -423,15 +423,34 @@ struct HipBackend {
         if (own_stream && stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
+    // Work queued on the stream in use so far is ordered before anything the new stream is given.
     void set_stream(void* s) {
+        hipStream_t ns = (hipStream_t)s;
+        if (ns == stream && !own_stream) return;
+        hipEvent_t e = get_event();
+        TEDD_HIP(hipEventRecord(e, stream));
+        TEDD_HIP(hipStreamWaitEvent(ns, e, 0));
+        event_pool.push_back(e);
         if (own_stream && stream) {
             (void)hipStreamSynchronize(stream);
             (void)hipStreamDestroy(stream);
         }
-        stream = (hipStream_t)s;
+        stream = ns;
         own_stream = false;
     }
     void use_device() { TEDD_HIP(hipSetDevice(device)); }
+    // The caller's current device, put back when an entry point returns (a host program that drives
+    // several devices must not find another one current after a call into this library).
+    struct DeviceKeeper {
+        int prev = -1;
+        DeviceKeeper() {
+            if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        }
+        ~DeviceKeeper() {
+            int now = -1;
+            if (prev >= 0 && hipGetDevice(&now) == hipSuccess && now != prev) (void)hipSetDevice(prev);
+        }
+    };
     // Address of the static scratch array on device `dev` (which must be the current device); looked up
     // once per device and kept for the life of the process.
     static double* scratch_on_device(int dev) {

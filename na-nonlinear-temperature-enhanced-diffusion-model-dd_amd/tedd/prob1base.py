@@ -338,11 +338,21 @@ class StateVars:
 
     def __init__(self, cp, T, cl, cd, cs, *, model, hh, kk):
         put = object.__setattr__
-        put(self, "_cp_data", np.asarray(cp))
-        put(self, "_T_data", np.asarray(T))
-        put(self, "_cl_data", np.asarray(cl))
-        put(self, "_cd_data", np.asarray(cd))
-        put(self, "_cs_data", np.asarray(cs))
+
+        def frozen(a):
+            # The device copy of a state and the field values computed from it are cached by the identity
+            # of the StateVars: an in-place edit of state.T[...] would go unseen, so it is made to fail.
+            a = np.asarray(a)
+            if not a.flags.writeable:
+                return a
+            v = a.view()
+            v.setflags(write=False)
+            return v
+        put(self, "_cp_data", frozen(cp))
+        put(self, "_T_data", frozen(T))
+        put(self, "_cl_data", frozen(cl))
+        put(self, "_cd_data", frozen(cd))
+        put(self, "_cs_data", frozen(cs))
         put(self, "_model", model)
         put(self, "_hh", hh)
         put(self, "_kk", kk)
@@ -428,7 +438,6 @@ class _Session:
         if key != self._sent:
             self.ctx.set_model(model.consts_vector(), model.model_kind, eta, mms_params)
             self._sent = key
-            self.state_token = None if self.state_token is None else self.state_token
 
     def load_state(self, state: StateVars):
         if self.state_token is not None and self.state_token is state:

@@ -490,3 +490,27 @@ def check_fixed_sweeps_are_plain_jacobi():
             np.testing.assert_array_equal(u, v)
     finally:
         ctx.close()
+
+
+def check_null_output_pointers_are_refused():
+    """Entry points that write through caller pointers refuse null ones with TEDD_ERR_INVALID (-1)."""
+    ctx = _ctx(12, 10, STIFF)
+    ctx.set_state_exact(0.0)
+    lib, h = ctx._lib, ctx._h
+    assert lib.tedd_state_device_ptrs(h, None) == -1
+    assert b"null" in lib.tedd_last_error(h)
+    assert lib.tedd_profile_get(h, 4, None, None, None) == -1
+    assert lib.tedd_profile_get(h, 0, None, None, None) == 0      # (room for nothing: nothing written)
+    ctx.close()
+
+
+def check_failed_create_releases_what_it_took():
+    """A context whose construction fails reports through tedd_last_error(NULL) and leaves the library usable."""
+    x = np.linspace(0, 1, 9)
+    for _ in range(3):
+        with pytest.raises(ValueError):
+            _ffi.Context(x[::-1].copy(), x, STIFF, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+                         mms_case=_ffi.MMS_EXPSIN)
+    ctx = _ctx(12, 10, STIFF)
+    ctx.set_state_exact(0.0)
+    ctx.close()

@@ -77,6 +77,7 @@ struct CpuBackend {
     }
     void sync() {}
     void sync_quiet() noexcept {}
+    struct DeviceKeeper {};
     void profile_enable(bool) {}
     void profile_collect() {}
 

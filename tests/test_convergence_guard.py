@@ -26,3 +26,11 @@ def test_warm_start_needs_fewer_sweeps_for_the_same_tolerance():
 
 def test_fixed_sweeps_are_not_judged_and_not_warm_started():
     cc.check_fixed_sweeps_are_plain_jacobi()
+
+
+def test_null_output_pointers_are_refused():
+    cc.check_null_output_pointers_are_refused()
+
+
+def test_failed_create_leaves_the_library_usable():
+    cc.check_failed_create_releases_what_it_took()

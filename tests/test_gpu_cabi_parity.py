@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import cabi_cases as cc
+from tedd import _ffi
 
 pytestmark = pytest.mark.gpu
 
@@ -96,6 +97,48 @@ def test_warm_start_needs_fewer_sweeps_for_the_same_tolerance(solver):
 
 def test_fixed_sweeps_are_not_judged_and_not_warm_started():
     cc.check_fixed_sweeps_are_plain_jacobi()
+
+
+def test_null_output_pointers_are_refused():
+    cc.check_null_output_pointers_are_refused()
+
+
+def test_failed_create_leaves_the_library_usable():
+    cc.check_failed_create_releases_what_it_took()
+
+
+def test_switching_streams_keeps_the_order_of_the_work():
+    """Steps enqueued on one caller stream, then the stream is switched without a synchronisation in
+    between: the steps on the new stream must see the results of the old one's."""
+    import torch
+    x = np.linspace(0, 1, 1025)
+    ref = _ffi.Context(x, x, cc.STIFF, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0, mms_case=_ffi.MMS_EXPSIN)
+    ref.set_state_exact(0.0)
+    for k in range(6):
+        ref.step_pc(k * 1e-3, 1e-3, jacobi_sweeps=(6, 4, 3))
+    want = ref.get_state()
+    ref.close()
+    ctx = _ffi.Context(x, x, cc.STIFF, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0, mms_case=_ffi.MMS_EXPSIN)
+    ctx.set_state_exact(0.0)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    for k in range(6):
+        ctx.set_stream(streams[k % 3].cuda_stream)
+        ctx.step_pc(k * 1e-3, 1e-3, jacobi_sweeps=(6, 4, 3))
+    got = ctx.get_state()
+    ctx.close()
+    for a, b in zip(want, got):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_calls_leave_the_callers_current_device_alone():
+    import torch
+    before = torch.cuda.current_device()
+    ctx = _ffi.Context(np.linspace(0, 1, 17), np.linspace(0, 1, 17), cc.STIFF, model_kind=2,
+                       reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0, mms_case=_ffi.MMS_EXPSIN, device=0)
+    ctx.set_state_exact(0.0)
+    ctx.step_pc(0.0, 1e-3)
+    ctx.close()
+    assert torch.cuda.current_device() == before
 
 
 # ---- exact solutions given as expression programs (TEDD_MMS_PROGRAM)

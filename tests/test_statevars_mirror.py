@@ -85,3 +85,14 @@ def test_with_changes_copy_and_into_dict():
     d = S.into_dict({}, which=["MxT", "cp"])
     assert set(d) == {"MxT", "cp"} and d["MxT"] is S.MxT
     assert set(S.into_dict({})) == set(DERIVED) | set(FIELDS)
+
+
+def test_state_arrays_cannot_be_edited_in_place():
+    """Device copies and field values are cached by the identity of the StateVars: an edit in place would
+    go unseen (the reference re-reads the arrays on every call), so it must fail."""
+    S, _model, _grid = make(1)
+    for v in ("cp", "T", "cl", "cd", "cs"):
+        with pytest.raises(ValueError):
+            getattr(S, v)[1, 1] = 3.0
+    S2 = S.with_changes(T=np.array(S.T))      # the way to change a state: a new one
+    assert S2.T is not S.T and S2.cp is S.cp
