@@ -113,7 +113,9 @@ int tedd_set_mms_program(tedd_ctx* ctx, int32_t which, const uint32_t* code, int
  * "march_occ": rows per segment and waves per SIMD of that launcher (0: the kernel's own choice);
  * "forcing_columns" (default 1): the forcing arrays of a closed-form case are made by threads that walk down
  * columns with the column's table entries in registers, on slabs large enough to fill the GPU that way
- * (0: one thread per node everywhere) -- bit-identical results. */
+ * (0: one thread per node everywhere) -- bit-identical results; "strip_panel" (default 8; 0: row-major):
+ * tile rows per panel of the order in which the solve launches' tiles are dealt to the GPU (down the columns of
+ * a panel first, so that the rows two tiles share are re-read from L2) -- same results. */
 int tedd_set_option(tedd_ctx* ctx, const char* name, double value);
 /* Use the caller's HIP stream (hipStream_t passed as void*) for all subsequent work. */
 int tedd_set_stream(tedd_ctx* ctx, void* hip_stream);

@@ -255,18 +255,35 @@ __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_R
         rmx[k] = 0.0;
         rmn[k] = INFINITY;
     }
+    // a workgroup walks over its tiles; the six values a node reads are requested one tile ahead, so that
+    // the iteration of the present tile runs while they travel
+    auto place = [&](int t, int& j, int& li) {
+        j = (t % tiles_x) * kTileX + threadIdx.x;
+        li = r0 + (t / tiles_x) * kTileY + threadIdx.y;
+        return j < ncols && li < r1;
+    };
+    CsNodeIn nxt{0, 0, 0, 0, 0, 0};
+    {
+        int j0, li0;
+        if (blockIdx.x < ntiles && place(blockIdx.x, j0, li0)) nxt = cs_node_load(a, at(a.g, li0, j0));
+    }
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int j = (t % tiles_x) * kTileX + threadIdx.x;
-        const int li = r0 + (t / tiles_x) * kTileY + threadIdx.y;
-        const bool active = (j < ncols && li < r1);
+        int j, li;
+        const bool active = place(t, j, li);
+        const CsNodeIn v = nxt;
+        {
+            int jn, lin;
+            const int tn = t + gridDim.x;
+            if (tn < ntiles && place(tn, jn, lin)) nxt = cs_node_load(a, at(a.g, lin, jn));
+        }
         double x = 0.0, y = 0.0, av = 0.0;
         bool in = false;
         size_t c = 0;
         if (active) {
             c = at(a.g, li, j);
             in = is_interior(a.g, li, j);
-            if (record) cp_out[c] = corrector_cp(a, li, j);
-            cs_newton_inputs(a, li, j, y, av, x);
+            if (record) put_once(cp_out + c, corrector_cp_vals(a.m, a.dt, v, in));
+            cs_newton_inputs_vals(a.m, a.dt, v, y, av, x);
         }
         double ex = active ? cs_newton_exp(x, a.m.eta) : 1.0;
         if (in_regs) {
@@ -304,7 +321,7 @@ __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_R
                 }
             }
         }
-        if (active) cs_out[c] = in ? x : 0.0 * x;
+        if (active) put_once(cs_out + c, in ? x : 0.0 * x);
     }
     if (record && in_regs) {
 #pragma unroll
@@ -370,6 +387,7 @@ struct HipBackend {
     // launcher's many small workgroups fill the GPU better), 0 never, 1 always
     int opt_march = -1;
     int opt_march_rows = 0;  // rows per segment (0: per functor, fewer on slabs with few rows)
+    int opt_strip_panel = 8;      // tile rows per panel of the strip launches' tile order (0: row-major)
     int opt_forcing_columns = 1;  // forcing arrays by column-walking threads (0: one thread per node)
     int opt_march_occ = 0;   // waves per SIMD the marching kernels' register budget is set for (0: per functor; 2, 3, 4)
     hipStream_t stream = nullptr;
@@ -834,7 +852,9 @@ struct HipBackend {
         A.tiles_x = (ncols + TIC - 1) / TIC;
         shape = strip_shape_for(VAR, A.H, A.r0, A.r1, ncols, shape);
         const int TIR = strip_tile_rows(shape) - 2 * A.H;
-        const long long nt = (long long)A.tiles_x * ((A.r1 - A.r0 + TIR - 1) / TIR);
+        A.tiles_y = (A.r1 - A.r0 + TIR - 1) / TIR;
+        A.panel = opt_strip_panel;
+        const long long nt = (long long)A.tiles_x * A.tiles_y;
         if (nt > 0x7fffffffLL) throw std::runtime_error("mesh too large for the tile index");
         const bool warm = (A.u_prev != nullptr);
         if (warm && A.stats_first == nullptr) throw std::runtime_error("warm strip solve needs a record slot");
@@ -891,6 +911,16 @@ struct HipBackend {
             unsigned long long* gmin = d_csstats + 4096;
             const size_t lds = (size_t)(iters > 0 ? 2 * iters : 2) * sizeof(unsigned long long);
             if (iters > 4096) throw std::runtime_error("more than 4096 cs Newton iterations");
+            // as many workgroups as the chip holds at once: each walks over an equal share of the tiles (a
+            // grid larger than that runs its surplus as a second, thinner round)
+            static int per_cu = 0;
+            if (per_cu == 0) {
+                int n = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cs_newton<CASE>, kTileX * kTileY, lds) != hipSuccess || n < 1)
+                    n = 4;
+                per_cu = n;
+            }
+            nb = std::min(nb, per_cu * num_cus);
             if (iters > 0 && cs_record_clean < iters)
                 hipLaunchKernelGGL(k_cs_init, dim3((iters + 255) / 256), dim3(256), 0, stream, gmax, gmin, iters);
             cs_record_clean = 0;

@@ -495,6 +495,8 @@ struct StripArgs {
     int H;           // halo depth of this launch
     int nsweeps;     // sweeps performed by this launch (<= H)
     int tiles_x;
+    int tiles_y = 1;
+    int panel = 0;   // tile rows per panel of the tile order (0: plain row-major order)
     unsigned long long* stats;
     // warm start (first launch of a chain only): the iteration starts from
     // delta^0 = gscale * (lagged unknown - u_prev), the increment of the time step before, instead of 0,
@@ -694,6 +696,25 @@ TEDD_HD double corrector_cs_sign_case(const CorrectIn<CASE, REACT>& a, int li, i
     return is_interior(a.g, li, j) ? v : 0.0 * v;
 }
 
+// the six values the RegHCsTriple corrector reads at a node, and the same formulas on them
+struct CsNodeIn {
+    double ncp, ycs, cs0, T1, cl1, cd1;
+};
+template <int CASE, int REACT>
+TEDD_HD CsNodeIn cs_node_load(const CorrectIn<CASE, REACT>& a, size_t c) {
+    return CsNodeIn{get_once(a.ncp + c), get_once(a.ycs + c), a.cs0[c], a.T1[c], a.cl1[c], a.cd1[c]};
+}
+TEDD_HD double corrector_cp_vals(const ModelC& m, double dt, const CsNodeIn& v, bool interior) {
+    if (!interior) return 0.0;
+    const double h = dt / 2;
+    const double al1 = -m.K2 * v.T1 - m.K1 * (v.cl1 + 1.0);
+    return tedd_div(v.ncp, 1.0 - h * al1);
+}
+TEDD_HD void cs_newton_inputs_vals(const ModelC& m, double dt, const CsNodeIn& v, double& y, double& av, double& x0) {
+    y = v.ycs;
+    av = dt * m.Kd * (m.Sd - v.cd1) * (v.cl1 + 1.0);
+    x0 = v.cs0;
+}
 // y and a of  2x + (2x - y) e^{-eta x} = y - a   (all nodes, boundary included)
 template <int CASE, int REACT>
 TEDD_HD void cs_newton_inputs(const CorrectIn<CASE, REACT>& a, int li, int j, double& y, double& av, double& x0) {

@@ -121,10 +121,24 @@ k_solve_strip(const StripArgs A) {
 
     // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2); give each XCD
     // a contiguous run of tiles so that neighbouring tiles' halos hit the same L2.
+    // The tiles are numbered in panels of A.panel tile rows, inside a panel down the columns first: a tile's
+    // neighbour below is the next workgroup of the XCD and its neighbour to the right follows A.panel
+    // workgroups later, so the rows and columns two tiles share (2H of a tile's 64 rows, re-read by the tile
+    // below) are found in the L2 while both are in flight, instead of a whole tile row later.
     const int nb = gridDim.x, bid = blockIdx.x;
     const int q = nb / 8, rem = nb % 8, xcd = bid % 8;
     const int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
-    const int ty = t / A.tiles_x, tx = t % A.tiles_x;
+    int ty, tx;
+    if (A.panel > 0) {
+        const int per_panel = A.panel * A.tiles_x;
+        const int p = t / per_panel, u = t - p * per_panel;
+        const int rows_p = min(A.panel, A.tiles_y - p * A.panel);  // (the last panel may be shorter)
+        tx = u / rows_p;
+        ty = p * A.panel + (u - tx * rows_p);
+    } else {
+        ty = t / A.tiles_x;
+        tx = t % A.tiles_x;
+    }
     const int row0 = A.r0 + ty * TIR - H + R * wave;  // local row of this thread's node k = 0
     const int j = tx * TIC - HC + lane;
     const int jc = min(max(j, 0), g.ncols - 1);

@@ -143,3 +143,14 @@ def test_expsin_cell_average_by_moments_matches_the_nine_point_sum():
     mesh = orc.Mesh(x, y)
     want = orc.forcing_arrays(orc.CaseExpSin(model), model, mesh, 2e-3, "reg", 30.0)["fcp"]
     assert np.abs(got - want).max() < 1e-15
+
+
+# ---- order in which the solve launches' tiles are dealt out
+@pytest.mark.parametrize("panel", [1, 3, 8, 1000])
+def test_tile_order_of_the_solve_launches_changes_nothing(panel):
+    """Panels of tile rows walked down the columns first (ragged last panel, panels taller than the mesh)
+    against the row-major order: the same tiles, so the same bits."""
+    ref, _ = _run_solve(300, 280, _ffi.REACT_REGHCSTRIPLE, {"strip_panel": 0}, steps=2, sweeps=(6, 4, 3))
+    got, _ = _run_solve(300, 280, _ffi.REACT_REGHCSTRIPLE, {"strip_panel": panel}, steps=2, sweeps=(6, 4, 3))
+    for a, b in zip(ref, got):
+        np.testing.assert_array_equal(a, b)
