@@ -107,6 +107,7 @@ __attribute__((amdgpu_waves_per_eu((FUSED ? StripShape<VAR, SHAPE>::OCC_FUSED : 
 k_solve_strip(const StripArgs A) {
     constexpr int R = StripShape<VAR, SHAPE>::R, W = StripShape<VAR, SHAPE>::W, TR = StripShape<VAR, SHAPE>::TR;
     constexpr bool LEAN = (VAR == VAR_T);
+    constexpr int kBatch = (R > 4) ? 4 : R;  // rows whose late loads (warm iterate, lagged unknown) are in flight together
     static_assert(!FUSED || (LAST && !LEAN && R == 4), "fused right-hand side: last launch of a cl/cd chain, 4-row strips");
     __shared__ double seam[2][W][2][kSTile];  // [parity][wave][first/last row of the strip][lane]
     __shared__ double2 rowc[LEAN ? TR : 1];  // lean rows: (dt J_e, dt J_w) of each tile row
@@ -330,11 +331,19 @@ k_solve_strip(const StripArgs A) {
         const double* uo_ = (VAR == VAR_T) ? A.a.To : (VAR == VAR_CL) ? A.a.clo : A.a.cdo;
         int jd = jc;
         asm volatile("" : "+v"(jd) : "v"(b[R - 1]));
+        // (a batch of loads first, unconditionally, then the masking: a select next to its load is compiled
+        // into a branch around the load, and the loads of a thread then wait for each other, one round trip
+        // each; batches of kBatch rows keep the loaded values within the register budget)
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const size_t c = (size_t)min(max(row0 + k, 0), rmax) * g.ld + jd;
-            const double v = A.gscale * ((FUSED ? uov[FUSED ? k + 1 : 0] : uo_[c]) - A.u_prev[c]);
-            d[k] = is_active(row0 + k) ? v : 0.0;
+        for (int k0 = 0; k0 < R; k0 += kBatch) {
+#pragma unroll
+            for (int k = k0; k < k0 + kBatch; ++k) {
+                const size_t c = (size_t)min(max(row0 + k, 0), rmax) * g.ld + jd;
+                d[k] = (FUSED ? uov[FUSED ? k + 1 : 0] : uo_[c]) - A.u_prev[c];
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = k0; k < k0 + kBatch; ++k) d[k] = is_active(row0 + k) ? A.gscale * d[k] : 0.0;
         }
     } else if (LEAN) {
     } else if (FUSED || A.d_in == A.b_in) {
@@ -344,10 +353,10 @@ k_solve_strip(const StripArgs A) {
         int jd = jc;
         asm volatile("" : "+v"(jd) : "v"(b[R - 1]));
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const double v = A.d_in[(size_t)min(max(row0 + k, 0), rmax) * g.ld + jd];
-            d[k] = is_active(row0 + k) ? v : 0.0;
-        }
+        for (int k = 0; k < R; ++k) d[k] = A.d_in[(size_t)min(max(row0 + k, 0), rmax) * g.ld + jd];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < R; ++k) d[k] = is_active(row0 + k) ? d[k] : 0.0;
     }
 
     // which of this thread's nodes are written back
@@ -381,11 +390,15 @@ k_solve_strip(const StripArgs A) {
         acc = fma(cn[k], lane_above(cur), acc);
         return fma(cs[k], lane_below(cur), acc);
     };
-    // (lean rows have the registers to fuse the final sweep with the store; full rows do it in place)
-    constexpr bool FUSE_FINAL = LAST && LEAN;
-    const int in_place = FUSE_FINAL ? max(A.nsweeps - 1, 0) : A.nsweeps;
+    // The last launch of a chain runs its final sweep apart from the others (it alone keeps the record
+    // max|delta^S - delta^(S-1)|), in place like them: fused with the store it would put each row's load of
+    // the lagged unknown between its update and its store, one memory round trip per row.
+    // (full rows of 16 nodes have no registers for a second copy of the sweep: their final sweep stays in the
+    // loop, told apart by a flag)
+    constexpr bool PEEL_FINAL = LAST && (LEAN || R == 4);
+    const int plain_end = PEEL_FINAL ? max(A.nsweeps - 1, 0) : A.nsweeps;
     int sw0 = 1;
-    if (WARM && in_place >= 1) {
+    if (WARM && plain_end >= 1) {
         // first sweep of a warm chain (a warm chain performs at least two): records max|delta^1 - delta^0|
         // over the rows and columns this launch writes back (nodes without an unknown contribute 0), reduced
         // per wave right away so that nothing of it stays live across the other sweeps
@@ -414,21 +427,36 @@ k_solve_strip(const StripArgs A) {
         }
         sw0 = 2;
     }
-    for (int sw = sw0; sw <= in_place; ++sw) {
+    for (int sw = sw0; sw <= plain_end; ++sw) {
         exchange_seams();
-        const bool track = LAST && !FUSE_FINAL && sw == A.nsweeps;
+        const bool track = LAST && !PEEL_FINAL && sw == A.nsweeps;
         double prev = above;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const double cur = d[k];
             const double v = update(k, prev, cur, (k < R - 1) ? d[k + 1] : below);
             d[k] = v;
-            if (track) {
+            if (LAST && !PEEL_FINAL && track) {
                 const int r = R * wave + k, li = row0 + k;
                 const bool counted = lane_in && r >= H && r < TR - H && li >= A.r0 && li < A.r1 && is_interior(g, li, j);
                 const double up = counted ? fabs(v - cur) : 0.0;
                 up_max = (up > up_max || up != up) ? up : up_max;
             }
+            prev = cur;
+        }
+    }
+    if (PEEL_FINAL && A.nsweeps >= 1) {
+        exchange_seams();
+        double prev = above;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double cur = d[k];
+            const double v = update(k, prev, cur, (k < R - 1) ? d[k + 1] : below);
+            d[k] = v;
+            const int r = R * wave + k, li = row0 + k;
+            const bool counted = lane_in && r >= H && r < TR - H && li >= A.r0 && li < A.r1 && is_interior(g, li, j);
+            const double up = counted ? fabs(v - cur) : 0.0;
+            up_max = (up > up_max || up != up) ? up : up_max;
             prev = cur;
         }
     }
@@ -439,44 +467,32 @@ k_solve_strip(const StripArgs A) {
     int row0w = row0, jw = j;
     asm volatile("" : "+s"(row0w));
     asm volatile("" : "+v"(jw));
-    if (FUSE_FINAL) {
-        // final sweep fused with the store: new unknown = lagged unknown + delta, boundary rule, and
-        // the record max|delta^S - delta^(S-1)|, max|delta^S| over the interior nodes written here
-        const bool sweep = A.nsweeps > 0;
-        if (sweep) exchange_seams();
+    if (LAST) {
+        // the lagged unknown of a batch of rows first (clamped coordinates, unconditional), then the stores
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const int r = R * wave + k;
-            const int li = row0w + k;
-            const double cur = d[k];
-            const double prev = (k > 0) ? d[k - 1] : above, nxt = (k < R - 1) ? d[k + 1] : below;
-            const double dn = sweep ? update(k, prev, cur, nxt) : cur;  // (all lanes take part in the lane shifts)
-            if (r >= H && r < TR - H && li >= A.r0 && li < A.r1 && lane_in) {
-                const size_t c = at(g, li, jw);
-                if (is_interior(g, li, jw)) {
-                    A.u_out[c] = uo[c] + dn;
-                    const double up = sweep ? fabs(dn - cur) : fabs(dn), mag = fabs(dn);
-                    up_max = (up > up_max || up != up) ? up : up_max;
-                    mag_max = (mag > mag_max || mag != mag) ? mag : mag_max;
-                } else {
-                    A.u_out[c] = (VAR == VAR_T) ? 0.0 : uo[c];
-                }
+        for (int k0 = 0; k0 < R; k0 += kBatch) {
+            double uold[kBatch];
+#pragma unroll
+            for (int k = k0; k < k0 + kBatch; ++k) {
+                if (FUSED)
+                    uold[k - k0] = uov[FUSED ? k + 1 : 0];
+                else
+                    uold[k - k0] = uo[(size_t)min(max(row0w + k, 0), rmax) * g.ld + min(max(jw, 0), g.ncols - 1)];
             }
-        }
-    } else if (LAST) {
+            asm volatile("" ::: "memory");
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const int r = R * wave + k;
-            const int li = row0w + k;
-            if (r >= H && r < TR - H && li >= A.r0 && li < A.r1 && lane_in) {
-                const size_t c = at(g, li, jw);
-                const double uold = FUSED ? uov[FUSED ? k + 1 : 0] : uo[c];
-                if (is_interior(g, li, jw)) {
-                    A.u_out[c] = uold + d[k];
-                    const double mag = fabs(d[k]);
-                    mag_max = (mag > mag_max || mag != mag) ? mag : mag_max;
-                } else {
-                    A.u_out[c] = (VAR == VAR_T) ? 0.0 : uold;
+            for (int k = k0; k < k0 + kBatch; ++k) {
+                const int r = R * wave + k;
+                const int li = row0w + k;
+                if (r >= H && r < TR - H && li >= A.r0 && li < A.r1 && lane_in) {
+                    const size_t c = at(g, li, jw);
+                    if (is_interior(g, li, jw)) {
+                        A.u_out[c] = uold[k - k0] + d[k];
+                        const double mag = fabs(d[k]);
+                        mag_max = (mag > mag_max || mag != mag) ? mag : mag_max;
+                    } else {
+                        A.u_out[c] = (VAR == VAR_T) ? 0.0 : uold[k - k0];
+                    }
                 }
             }
         }

@@ -1,0 +1,31 @@
+"""Time of the single-launch Newton solves as a function of their depth (fixed sweep counts, cold start).
+
+    python3 tools/solve_depth_probe.py [N]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "na-nonlinear-temperature-enhanced-diffusion-model-dd_amd"))
+import bench  # noqa: E402
+from tedd import _ffi  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+x = np.linspace(0, 1, N + 1)
+ctx = _ffi.Context(x, x, bench.consts_vec(bench.NB_A), model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+                   mms_case=_ffi.MMS_EXPSIN)
+dt = (1.0 / N) ** 1.5
+ctx.set_state_exact(0.0)
+for s in (1, 2, 3, 4, 6, 8, 10):
+    ctx.set_state_exact(0.0)
+    ctx.step_pc(0.0, dt, jacobi_sweeps=(s, s, s))
+    ctx.profile_enable(True)
+    for k in range(4):
+        ctx.step_pc((k + 1) * dt, dt, jacobi_sweeps=(s, s, s))
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+    print(s, " ".join("%s=%.3f" % (k, v["total_ms"] / v["launches"]) for k, v in prof.items() if k.startswith("solve")), flush=True)
+ctx.close()
