@@ -387,6 +387,7 @@ struct HipBackend {
     // launcher's many small workgroups fill the GPU better), 0 never, 1 always
     int opt_march = -1;
     int opt_march_rows = 0;  // rows per segment (0: per functor, fewer on slabs with few rows)
+    int opt_march_ahead = -1;     // marching kernels request the next row a row ahead (-1: per functor)
     int opt_strip_panel = 8;      // tile rows per panel of the strip launches' tile order (0: row-major)
     int opt_forcing_columns = 1;  // forcing arrays by column-walking threads (0: one thread per node)
     int opt_march_occ = 0;   // waves per SIMD the marching kernels' register budget is set for (0: per functor; 2, 3, 4)
@@ -703,15 +704,23 @@ struct HipBackend {
                 // register budget: the functor's own choice unless an option overrides it.  Three builds of
                 // the kernel: 2 waves per SIMD with the next row requested a row ahead, 3 and 4 without.
                 const int occ = opt_march_occ > 0 ? opt_march_occ : F::kMarchOcc;
+                const bool ahead = opt_march_ahead >= 0 ? opt_march_ahead != 0 : (occ <= 2 || F::kMarchAhead);
+                auto go = [&](auto occ_c, auto ahead_c) {
+                    hipLaunchKernelGGL((k_march<F, decltype(occ_c)::value, decltype(ahead_c)::value>), dim3((unsigned)nt),
+                                       dim3(64, kMarchWaves), 0, stream, f, r0, r1, ncols, seg, tiles_x);
+                };
+                auto by_ahead = [&](auto occ_c) {
+                    if (ahead)
+                        go(occ_c, std::true_type{});
+                    else
+                        go(occ_c, std::false_type{});
+                };
                 if (occ <= 2)
-                    hipLaunchKernelGGL((k_march<F, 2, true>), dim3((unsigned)nt), dim3(64, kMarchWaves), 0, stream, f, r0, r1,
-                                       ncols, seg, tiles_x);
+                    by_ahead(std::integral_constant<int, 2>{});
                 else if (occ == 3)
-                    hipLaunchKernelGGL((k_march<F, 3, false>), dim3((unsigned)nt), dim3(64, kMarchWaves), 0, stream, f, r0, r1,
-                                       ncols, seg, tiles_x);
+                    by_ahead(std::integral_constant<int, 3>{});
                 else
-                    hipLaunchKernelGGL((k_march<F, 4, false>), dim3((unsigned)nt), dim3(64, kMarchWaves), 0, stream, f, r0, r1,
-                                       ncols, seg, tiles_x);
+                    by_ahead(std::integral_constant<int, 4>{});
                 TEDD_HIP(hipGetLastError());
                 return;
             }

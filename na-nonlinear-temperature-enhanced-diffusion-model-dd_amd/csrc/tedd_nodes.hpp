@@ -38,6 +38,24 @@ TEDD_HD St5 load5(const double* u, const GridDev& g, int li, int j) {
     const size_t c = at(g, li, j);
     return St5{u[c], u[c + g.ld], u[c - g.ld], u[c + 1], u[c - 1]};
 }
+// The same at any node of the slab: neighbours outside it are replaced by the node itself (they are only
+// used at interior nodes, which have all four), so the five loads need no condition around them.
+TEDD_HD Geo geo_at_clamped(const GridDev& g, int li, int j) {
+    const int le = (li + 1 < g.nrows) ? li + 1 : li, jn = (j + 1 < g.ncols) ? j + 1 : j;
+    return Geo{g.rh[li], g.rh[le], g.rhm[li], g.rk[j], g.rk[jn], g.rkm[j]};
+}
+TEDD_HD St5 load5_clamped(const double* u, const GridDev& g, int li, int j) {
+    const int le = (li + 1 < g.nrows) ? li + 1 : li, lw = (li > 0) ? li - 1 : li;
+    const int jn = (j + 1 < g.ncols) ? j + 1 : j, js = (j > 0) ? j - 1 : j;
+    return St5{u[at(g, li, j)], u[at(g, le, j)], u[at(g, lw, j)], u[at(g, li, jn)], u[at(g, li, js)]};
+}
+TEDD_HD void loads_done() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Loads written before this point are issued before it: without it the compiler moves each load into the
+    // conditional block that uses its value, and a thread then waits for its loads one block after the other.
+    asm volatile("" ::: "memory");
+#endif
+}
 
 struct Fields5 {  // cp, T, cl, cd, cs
     const double* v[5];
@@ -183,6 +201,40 @@ struct PredictFn {
     TEDD_HD void operator()(int li, int j) const {
         const bool in = is_interior(g, li, j);
         const size_t c = at(g, li, j);
+        if (CASE == CASE_STREAM) {
+            // array-fed forcing: everything the node reads is requested at once, whatever kind of node it is
+            // (on a small mesh the launch is as long as its longest chain of dependent loads), then the
+            // arithmetic of the marching launcher's node body
+            const St5 cp = load5_clamped(S.v[VAR_CP], g, li, j), T = load5_clamped(S.v[VAR_T], g, li, j);
+            const St5 cl = load5_clamped(S.v[VAR_CL], g, li, j), cd = load5_clamped(S.v[VAR_CD], g, li, j);
+            const double cs0 = S.v[VAR_CS][c];
+            const Forcing5 fa{get_once(f0.f[0] + c), get_once(f0.f[1] + c), get_once(f0.f[2] + c),
+                              get_once(f0.f[3] + c), get_once(f0.f[4] + c)};
+            double fcp1 = 0.0, fcs1 = 0.0, fT1 = 0.0;
+            if (FCASE == CASE_STREAM) {
+                fcp1 = get_once(f1.f[0] + c);
+                fcs1 = get_once(f1.f[4] + c);
+                if (bT) fT1 = get_once(f1.f[1] + c);
+            }
+            const Geo ge = geo_at_clamped(g, li, j);
+            loads_done();
+            if (FCASE != CASE_STREAM) {
+                const Forcing5 fb = node_forcing<FCASE, REACT>(m, tb, f1, g, li, j, in, true);
+                fcp1 = fb.fcp;
+                fcs1 = fb.fcs;
+                fT1 = fb.fT;
+                put_once(f1_out.v[0] + c, fb.fcp);
+                put_once(f1_out.v[1] + c, fb.fT);
+                put_once(f1_out.v[2] + c, fb.fcl);
+                put_once(f1_out.v[3] + c, fb.fcd);
+                put_once(f1_out.v[4] + c, fb.fcs);
+            }
+            const F5 F = node_field_vals<REACT>(m, ge, cp, T, cl, cd, cs0, fa, in);
+            St5 Tb{T.c, 0.0, 0.0, 0.0, 0.0};
+            if (bT && in) Tb = T;
+            finish(c, in, ge, F, fa, cp.c, Tb, cl.c, cd.c, cs0, fcp1, fcs1, fT1);
+            return;
+        }
         Forcing5 fa = node_forcing<CASE, REACT>(m, tb, f0, g, li, j, in, fcp_t0 == nullptr);
         if (CASE != CASE_STREAM && fcp_t0 != nullptr) fa.fcp = fcp_t0[c];
         const F5 F = node_field<REACT>(m, g, S, fa, li, j, in);
@@ -271,6 +323,7 @@ struct PredictFn {
     static constexpr bool kMarches = (CASE == CASE_STREAM && FCASE == CASE_STREAM);
     // measured best at 16384^2: two waves per SIMD (the body needs ~180 registers) and 128-row segments
     static constexpr int kMarchOcc = 2, kMarchRows = 128;
+    static constexpr bool kMarchAhead = false;
     static constexpr int NS = 4, NC = 9;
     TEDD_HD const double* sptr(int k) const { return S.v[k]; }  // cp, T, cl, cd
     TEDD_HD const double* cptr(int k) const {
@@ -450,7 +503,8 @@ struct NewtonRhsFn {
 
     // ---- interface of the marching launcher (tedd_march.hpp): cl and cd systems with array-fed forcing
     static constexpr bool kMarches = (CASE == CASE_STREAM && VAR != VAR_T);
-    static constexpr int kMarchOcc = (VAR == VAR_CL) ? 4 : 3, kMarchRows = 64;  // (measured best at 16384^2)
+    static constexpr int kMarchOcc = (VAR == VAR_CL) ? 4 : 3, kMarchRows = 64;
+    static constexpr bool kMarchAhead = false;  // (measured best at 16384^2)
     static constexpr int NS = 4;                       // cp*, lagged T, lagged unknown, new T
     static constexpr int NC = (VAR == VAR_CL) ? 2 : 5;  // Y, forcing | + lagged cl, cs*, new cl
     TEDD_HD const double* sptr(int k) const {

@@ -260,11 +260,24 @@ k_solve_strip(const StripArgs A) {
         const int i = g.i0 + li;
         return col_interior && li >= 1 && li <= g.nrows - 2 && i >= 1 && i <= g.N - 1;
     };
+    // (short strips: the row metrics of all R rows are requested together, ahead of the loop that uses them
+    // one row at a time)
+    constexpr bool GEO_AHEAD = (R == 4);
+    double rhv[GEO_AHEAD ? R + 1 : 1], rhmv[GEO_AHEAD ? R : 1];
+    if (GEO_AHEAD) {
+#pragma unroll
+        for (int k = 0; k <= R; ++k) rhv[GEO_AHEAD ? k : 0] = g.rh[min(max(row0 + k, 0), rmax)];
+#pragma unroll
+        for (int k = 0; k < R; ++k) rhmv[GEO_AHEAD ? k : 0] = g.rhm[min(max(row0 + k, 0), rmax)];
+        loads_done();
+    }
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int li = row0 + k;
         const int lic = min(max(li, 0), rmax);
-        const Geo ge{g.rh[lic], g.rh[min(lic + 1, rmax)], g.rhm[lic], rks, rkn, rkm};
+        // (rhv[k + 1] is g.rh[min(lic + 1, rmax)] at every row that has an unknown)
+        const Geo ge = GEO_AHEAD ? Geo{rhv[GEO_AHEAD ? k : 0], rhv[GEO_AHEAD ? k + 1 : 0], rhmv[GEO_AHEAD ? k : 0], rks, rkn, rkm}
+                                 : Geo{g.rh[lic], g.rh[min(lic + 1, rmax)], g.rhm[lic], rks, rkn, rkm};
         const bool active = is_active(li);
         Coef5 r;
         if (LEAN) {
