@@ -115,7 +115,14 @@ int tedd_set_mms_program(tedd_ctx* ctx, int32_t which, const uint32_t* code, int
  * columns with the column's table entries in registers, on slabs large enough to fill the GPU that way
  * (0: one thread per node everywhere) -- bit-identical results; "strip_panel" (default 8; 0: row-major):
  * tile rows per panel of the order in which the solve launches' tiles are dealt to the GPU (down the columns of
- * a panel first, so that the rows two tiles share are re-read from L2) -- same results. */
+ * a panel first, so that the rows two tiles share are re-read from L2) -- same results; "persistent" (default
+ * 0; RegHCsTriple, whole-mesh contexts of at most 4 M nodes, at most 8 cs Newton iterations; other calls keep
+ * separate launches): the launches of the predictor-corrector steps of one call (tedd_step_pc, tedd_advance
+ * with its norms) are recorded and run as ONE persistent launch -- 1: one workgroup, phases separated by the
+ * workgroup barrier; k > 1: k workgroups and a barrier over the grid -- with the per-sweep solver from zero
+ * iterates, bit-identical to "strip_solve" 0 + "warm_start" 0.  Slower than separate launches on every mesh
+ * measured on MI355X, hence off; a grid barrier that does not fill within ~0.2 s (compute units held by
+ * another program) ends the launch and the next synchronising call returns TEDD_ERR_RUNTIME. */
 int tedd_set_option(tedd_ctx* ctx, const char* name, double value);
 /* Use the caller's HIP stream (hipStream_t passed as void*) for all subsequent work. */
 int tedd_set_stream(tedd_ctx* ctx, void* hip_stream);

@@ -24,7 +24,19 @@ int guarded(tedd_ctx* c, Fn&& fn) {
     typename TEDD_BACKEND::DeviceKeeper keep;
     try {
         c->impl->be.use_device();
-        fn(*c->impl);
+        try {
+            fn(*c->impl);
+        } catch (...) {
+            // launches recorded for the persistent step kernel before the call failed still run: the steps
+            // completed so far stand, as they do with separate launches
+            try {
+                c->impl->be.rec_end();
+            } catch (...) {
+                c->impl->be.rec_discard();
+            }
+            throw;
+        }
+        c->impl->be.rec_end();
         return TEDD_OK;
     } catch (const tedd::AssertError& e) {
         c->err = e.what();

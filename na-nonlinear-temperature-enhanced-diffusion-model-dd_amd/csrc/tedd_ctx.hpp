@@ -136,7 +136,7 @@ public:
     // then runs closer to the HBM roofline).  -1: fuse up to 4 M nodes per slab.
     int opt_fuse_forcing = -1;
     bool fuse_forcing_now() const {
-        if (mms_case == CASE_PROG) return false;
+        if (mms_case == CASE_PROG || persist_step) return false;
         return opt_fuse_forcing < 0 ? (size_t)nrows * ncols <= ((size_t)1 << 22) : opt_fuse_forcing != 0;
     }
     bool predict_makes_f1 = false;
@@ -579,7 +579,7 @@ public:
         }
         double* gone[3] = {prev[0], prev[1], prev[2]};
         for (int v = 0; v < 3; ++v) prev[v] = nullptr;
-        if (keep_old_as_prev && opt_warm) {
+        if (keep_old_as_prev && opt_warm && !persist_step) {
             for (int v = 0; v < 3; ++v) prev[v] = (old[VAR_T + v] != cur[VAR_T + v]) ? old[VAR_T + v] : nullptr;
             prev_dt = dt;
         } else {
@@ -900,7 +900,8 @@ public:
     void choose_sweeps(StepParams& p, const int32_t* sweeps_in, double jtol, int jmax, StepMeta& mt) {
         const double dcoef[3] = {model.DT, model.Dl_max, model.Dd_max};
         const bool partial = (gl > 0 || gr > 0);
-        const bool can_warm = opt_warm && p.num_pc > 0 && p.num_newton > 0 && prev_dt > 0.0 && next_seq > chain_start;
+        const bool can_warm = opt_warm && !persist_step && p.num_pc > 0 && p.num_newton > 0 && prev_dt > 0.0 &&
+                              next_seq > chain_start;
         double upd[3], inc[3], first[3];
         bool have_rec = false;
         bool asked = false;
@@ -976,6 +977,16 @@ public:
         StepParams p{t0, dt, num_pc, num_newton, cs_iters, cs_rtol, {0, 0, 0}};
         StepMeta mt;
         mt.seq = next_seq;
+        const int pgroups = persist_groups(num_pc, num_newton, cs_iters);
+        struct PersistGuard {
+            bool& flag;
+            ~PersistGuard() { flag = false; }
+        } persist_guard{persist_step};
+        persist_step = pgroups > 0;
+        if (persist_step) {
+            drop_prev();  // (recorded steps start their solves from zero: no history is kept or read)
+            be.rec_begin(react, pgroups);
+        }
         choose_sweeps(p, sweeps_in, jtol, jmax, mt);
         // prologue: fold and publish the record of the step before, clear the records of this one
         {
@@ -1153,6 +1164,29 @@ public:
         return opt_fuse_rhs < 0 ? (size_t)nrows * ncols <= ((size_t)1 << 22) : opt_fuse_rhs != 0;
     }
     bool bT_ready = false;    // slot DA holds rhs/diag of the next T system (written by the predictor launch)
+    // Persistent step kernel (backends that have it, tedd_persist.hpp): the launches of the step are recorded
+    // and run as one launch per entry-point call (or per kRecCap recorded launches), by the per-sweep solver
+    // from zero iterates.  0 (default): off; 1: one workgroup (the barrier between phases is the workgroup
+    // barrier); k > 1: k workgroups and a barrier over the grid.  Off by default because it is slower than the
+    // separate launches on every mesh measured (MI355X, microseconds per step, launches / persistent with the
+    // best number of workgroups: 8^2 50 / 65, 32^2 48 / 107, 64^2 50 / 136, 256^2 60 / 232): a phase boundary
+    // inside the launch costs more than a kernel boundary, and there are 17-25 of them per step.
+    int opt_persistent = 0;
+    bool persist_step = false;  // the step being sequenced is recorded
+    bool strip_now() const { return opt_strip && !persist_step; }
+    int persist_groups(int num_pc, int num_newton, int cs_iters) const {
+        if constexpr (!Backend::kHasPersist) {
+            return 0;
+        } else {
+            const int groups = opt_persistent;
+            if (groups <= 0) return 0;
+            if (!Backend::persist_react_ok(react) || num_pc < 1 || num_newton < 1) return 0;
+            if (gl > 0 || gr > 0 || be.reduce_hook || be.profiling) return 0;
+            if (mms_case != CASE_STREAM && !(opt_cache_forcing || mms_case == CASE_PROG)) return 0;
+            if (cs_iters > 8 || (long long)nrows * ncols > (1LL << 22)) return 0;
+            return groups;
+        }
+    }
 
     // Register-resident solve chain (tedd_strip.hpp): b = delta^1 = rhs/diag from the node kernel,
     // then ceil((nsweeps-1)/hmax) launches that iterate on (b, delta).
@@ -1252,7 +1286,7 @@ public:
     void newton_solve(const StepParams& p, const ForcingSrc& f1, const NewtonIn& a, double* unew, int nsweeps, int slot_id,
                       const double* u_prev = nullptr) {
         if constexpr (Backend::kHasStripSolve) {
-            if (opt_strip) {
+            if (strip_now()) {
                 newton_solve_strip<VAR, CASE, REACT>(p, f1, a, unew, nsweeps, slot_id, u_prev);
                 return;
             }
@@ -1363,7 +1397,7 @@ public:
             // the register-resident solve iterates on b = rhs/diag; for the first T system the predictor
             // kernel has everything b needs
             double* bT = nullptr;
-            if (Backend::kHasStripSolve && opt_strip && p.num_pc > 0 && p.num_newton > 0) bT = B(DA);
+            if (Backend::kHasStripSolve && strip_now() && p.num_pc > 0 && p.num_newton > 0) bT = B(DA);
             bool launched = false;
             if constexpr (CASE == CASE_STREAM) {
                 if (predict_makes_f1) {
@@ -1683,6 +1717,9 @@ public:
                 else
                     be.opt_march_occ = (int)value;
             }
+        } else if (name == "persistent") {
+            opt_persistent = (int)value;
+            bT_ready = false;
         } else if (name == "warm_start") {
             opt_warm = value != 0.0;
             if (!opt_warm) drop_prev();

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -165,7 +166,11 @@ __global__ void k_cs_init(unsigned long long* gmax, unsigned long long* gmin, in
 // synchronising with the stream), then clears the record of the Newton solves and that of the cs corrector.
 __device__ __forceinline__ void step_prologue_body(const StepRecordArgs& a, unsigned long long* gmax,
                                                    unsigned long long* gmin, int k, int nthreads, double* rec /*LDS, 16*/) {
-    if (k < 16) rec[k] = a.red[k];
+    // (the record words are raised by atomics, which do not pass through this compute unit's L1: read them
+    // past it, or a launch that runs several steps finds the zeros it stored itself a step earlier)
+    if (k < 16)
+        rec[k] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.red) + k,
+                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     __syncthreads();
     if (k < 3 && a.fold) fold_record(a, rec, k);
     if (k == 0 && a.ring_slot) {
@@ -375,6 +380,10 @@ struct CorrectClosedFn {
     }
 };
 
+}  // namespace tedd
+#include "tedd_persist.hpp"
+namespace tedd {
+
 // node functors that provide the marching interface (tedd_march.hpp)
 template <class F, class = void>
 struct Marches : std::false_type {};
@@ -412,6 +421,107 @@ struct HipBackend {
     double fam_ms[FAM_COUNT] = {0};
     long long fam_n[FAM_COUNT] = {0};
 
+    // ---- persistent step kernel (tedd_persist.hpp): while `rec_on`, launches the kernel can run are recorded
+    // as descriptors instead of being launched; anything else this backend is asked to do first sends what was
+    // recorded to the device as one launch (flush_record), so the order of the stream is kept.
+    static constexpr bool kHasPersist = true;
+    static constexpr size_t kRecCap = 1024;  // descriptors per launch
+    bool rec_on = false;
+    int rec_react = -1;
+    int rec_groups = 1;  // workgroups of the launch
+    std::vector<PDesc> rec;
+    PDesc* d_descs = nullptr;
+    PDesc* h_descs[2] = {nullptr, nullptr};  // pinned staging, used in turn
+    hipEvent_t h_descs_ev[2] = {nullptr, nullptr};
+    bool h_descs_busy[2] = {false, false};
+    int h_descs_next = 0;
+    unsigned* d_pwords = nullptr;  // [0] barrier counter, [1] abort word
+    unsigned pbar_base = 0;
+    int* h_pabort = nullptr;       // host-visible: a barrier of a persistent launch timed out
+    int* d_pabort = nullptr;       // ... as the device addresses it
+    long long persist_launches = 0, persist_descs = 0;
+
+    static bool persist_react_ok(int react) { return react == REACT_REG; }
+    void rec_begin(int react, int groups) {
+        if (!persist_react_ok(react)) return;
+        groups = std::max(1, std::min(groups, num_cus));
+        if (rec_on && (react != rec_react || groups != rec_groups)) flush_record();
+        if (!d_descs) {
+            d_descs = (PDesc*)alloc(kRecCap * sizeof(PDesc));
+            for (int k = 0; k < 2; ++k) {
+                TEDD_HIP(hipHostMalloc((void**)&h_descs[k], kRecCap * sizeof(PDesc), hipHostMallocDefault));
+                TEDD_HIP(hipEventCreateWithFlags(&h_descs_ev[k], hipEventDisableTiming));
+            }
+            d_pwords = (unsigned*)alloc(64);
+            TEDD_HIP(hipMemsetAsync(d_pwords, 0, 64, stream));
+            h_pabort = (int*)alloc_host_visible(64);
+            d_pabort = (int*)device_view(h_pabort);
+            rec.reserve(kRecCap);
+        }
+        rec_react = react;
+        rec_groups = groups;
+        rec_on = true;
+    }
+    // end of an entry point: what was recorded runs now
+    void rec_end() {
+        if (!rec_on) return;
+        rec_on = false;
+        flush_record();
+    }
+    void rec_discard() noexcept {
+        rec_on = false;
+        rec.clear();
+    }
+    PDesc& rec_push(int op, int ftype, int barrier, int r0, int r1, int ncols) {
+        if (rec.size() >= kRecCap) flush_record();
+        rec.emplace_back();
+        PDesc& d = rec.back();
+        std::memset(&d, 0, offsetof(PDesc, f));
+        d.op = op;
+        d.ftype = ftype;
+        d.barrier = barrier;
+        d.r0 = r0;
+        d.r1 = r1;
+        d.ncols = ncols;
+        return d;
+    }
+    template <class F>
+    static void rec_functor(PDesc& d, const F& f) {
+        static_assert(sizeof(F) <= kPFunctorBytes, "functor larger than a descriptor holds");
+        static_assert(std::is_trivially_copyable<F>::value, "functors are copied bytewise");
+        std::memcpy(d.f, &f, sizeof(F));
+    }
+    void flush_record() {
+        if (rec.empty()) return;
+        const int slot = h_descs_next;
+        h_descs_next ^= 1;
+        if (h_descs_busy[slot]) TEDD_HIP(hipEventSynchronize(h_descs_ev[slot]));
+        const size_t n = rec.size();
+        std::memcpy(h_descs[slot], rec.data(), n * sizeof(PDesc));
+        unsigned barriers = 0;
+        for (const PDesc& d : rec) barriers += d.barrier ? 1u : 0u;
+        rec.clear();
+        TEDD_HIP(hipMemcpyAsync(d_descs, h_descs[slot], n * sizeof(PDesc), hipMemcpyHostToDevice, stream));
+        TEDD_HIP(hipEventRecord(h_descs_ev[slot], stream));
+        h_descs_busy[slot] = true;
+        PersistCtl ctl{d_pwords, pbar_base, d_pabort, d_csstats, d_csstats + 4096};
+        hipLaunchKernelGGL(k_persist<REACT_REG>, dim3(rec_groups), dim3(64, kPWaves), 0, stream, d_descs, (int)n, ctl);
+        TEDD_HIP(hipGetLastError());
+        if (rec_groups > 1) pbar_base += barriers * (unsigned)rec_groups;
+        persist_launches += 1;
+        persist_descs += (long long)n;
+    }
+    void check_persist_abort() {
+        if (h_pabort && *(volatile int*)h_pabort != 0) {
+            *(volatile int*)h_pabort = 0;
+            (void)hipMemsetAsync(d_pwords, 0, 64, stream);
+            (void)hipStreamSynchronize(stream);
+            pbar_base = 0;
+            throw std::runtime_error("persistent step kernel: a grid barrier timed out (workgroups not all resident); "
+                                     "the state is undefined, set it again (option persistent = 0 uses separate launches)");
+        }
+    }
+
     void init(int dev) {
         int cur = 0;
         TEDD_HIP(hipGetDevice(&cur));
@@ -433,6 +543,19 @@ struct HipBackend {
         for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
         free(d_partials);
         free(d_csstats);
+        free(d_descs);
+        free(d_pwords);
+        d_descs = nullptr;
+        d_pwords = nullptr;
+        for (int k = 0; k < 2; ++k) {
+            if (h_descs[k]) (void)hipHostFree(h_descs[k]);
+            if (h_descs_ev[k]) (void)hipEventDestroy(h_descs_ev[k]);
+            h_descs[k] = nullptr;
+            h_descs_ev[k] = nullptr;
+        }
+        if (h_pabort) free_host_visible(h_pabort);
+        h_pabort = nullptr;
+        rec_discard();
         free(d_stage);
         d_stage = nullptr;
         stage_elems = 0;
@@ -445,6 +568,7 @@ struct HipBackend {
     // Work queued on the stream in use so far is ordered before anything the new stream is given.
     void set_stream(void* s) {
         hipStream_t ns = (hipStream_t)s;
+        flush_record();
         if (ns == stream && !own_stream) return;
         hipEvent_t e = get_event();
         TEDD_HIP(hipEventRecord(e, stream));
@@ -493,12 +617,19 @@ struct HipBackend {
     void free(void* p) {
         if (p) (void)hipFree(p);
     }
-    void memset0(void* p, size_t bytes) { TEDD_HIP(hipMemsetAsync(p, 0, bytes, stream)); }
+    void memset0(void* p, size_t bytes) {
+        flush_record();
+        TEDD_HIP(hipMemsetAsync(p, 0, bytes, stream));
+    }
     // prologue of a step: fold / publish the record of the step before, clear the records (k_step_prologue)
     void step_prologue(StepRecordArgs a) {
         if (a.cs_iters > 4096) a.cs_iters = 0;  // (refused later, by correct)
-        hipLaunchKernelGGL(k_step_prologue, dim3(1), dim3(256), 0, stream, a, d_csstats, d_csstats + 4096);
-        TEDD_HIP(hipGetLastError());
+        if (rec_on) {
+            rec_functor(rec_push(PO_PROLOGUE, 0, 1, 0, 0, 0), a);
+        } else {
+            hipLaunchKernelGGL(k_step_prologue, dim3(1), dim3(256), 0, stream, a, d_csstats, d_csstats + 4096);
+            TEDD_HIP(hipGetLastError());
+        }
         if (a.clear) cs_record_clean = a.cs_iters;
     }
     // the predictor launch with the step's prologue folded into its first workgroup; where the launch is a
@@ -517,6 +648,17 @@ struct HipBackend {
             return;
         }
         if (a.cs_iters > 4096) a.cs_iters = 0;  // (refused later, by correct)
+        if (rec_on) {
+            constexpr int kind = IndexOf<F, PNodeList<REACT_REG>>::value;
+            if constexpr (kind >= 0) {
+                // (the prologue and the predictor touch different data: no barrier between them, as in the one launch)
+                rec_functor(rec_push(PO_PROLOGUE, 0, 1, 0, 0, 0), a);
+                rec_functor(rec_push(PO_NODES, kind, 0, r0, r1, ncols), f);
+                if (a.clear) cs_record_clean = a.cs_iters;
+                return;
+            }
+            flush_record();
+        }
         Scope sc(this, fam);
         dim3 block(kTileX, kTileY), grid((ncols + kTileX - 1) / kTileX, (r1 - r0 + kTileY - 1) / kTileY);
         hipLaunchKernelGGL(k_nodes_pro<F>, grid, block, 0, stream, f, r0, r1, ncols, a, d_csstats, d_csstats + 4096);
@@ -539,10 +681,14 @@ struct HipBackend {
         return d;
     }
     void h2d(void* d, const void* s, size_t bytes) {
+        flush_record();
         TEDD_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream));
         TEDD_HIP(hipStreamSynchronize(stream));  // the source may be a temporary
     }
-    void d2h(void* d, const void* s, size_t bytes) { TEDD_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream)); }
+    void d2h(void* d, const void* s, size_t bytes) {
+        flush_record();
+        TEDD_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream));
+    }
     // Host arrays are dense, device arrays pitched.  A 2-D copy between the two is executed row by row
     // (1.7 ms for a 257 x 257 field); instead the rows are (un)packed on the device through a staging
     // array and cross PCIe as one block.  All of it is ordered on the context's stream.
@@ -560,12 +706,14 @@ struct HipBackend {
         return d_stage;
     }
     void copy_rows(double* d, size_t dpitch, const double* s, size_t spitch, int width, int rows) {
+        flush_record();
         dim3 block(64, 4), grid((width + 63) / 64, std::min((rows + 3) / 4, 65535));
         hipLaunchKernelGGL(k_copy_rows, grid, block, 0, stream, d, dpitch, s, spitch, width, rows);
         TEDD_HIP(hipGetLastError());
     }
     void h2d_2d(double* d, size_t dpitch, const double* s, size_t spitch, int width, int rows) {
         if (rows <= 0 || width <= 0) return;
+        flush_record();
         const size_t n = (size_t)rows * width;
         if (spitch == (size_t)width && dpitch == (size_t)width) {
             TEDD_HIP(hipMemcpyAsync(d, s, n * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -581,6 +729,7 @@ struct HipBackend {
     }
     void d2h_2d(double* d, size_t dpitch, const double* s, size_t spitch, int width, int rows) {
         if (rows <= 0 || width <= 0) return;
+        flush_record();
         const size_t n = (size_t)rows * width;
         if (spitch == (size_t)width && dpitch == (size_t)width) {
             TEDD_HIP(hipMemcpyAsync(d, s, n * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -593,7 +742,11 @@ struct HipBackend {
                                       (size_t)width * sizeof(double), rows, hipMemcpyDeviceToHost, stream));
         }
     }
-    void sync() { TEDD_HIP(hipStreamSynchronize(stream)); }
+    void sync() {
+        flush_record();
+        TEDD_HIP(hipStreamSynchronize(stream));
+        check_persist_abort();
+    }
     void sync_quiet() noexcept {
         if (stream) (void)hipStreamSynchronize(stream);
     }
@@ -606,6 +759,7 @@ struct HipBackend {
         int wanted = 0;
         for (int v = 0; v < count; ++v) wanted += dst[v] != nullptr;
         if (wanted == 0) return;
+        flush_record();
         if (n * wanted * sizeof(double) > ((size_t)32 << 20)) {
             for (int v = 0; v < count; ++v)
                 if (dst[v]) d2h_2d(dst[v], width, src[v], spitch, width, rows);
@@ -667,6 +821,7 @@ struct HipBackend {
         profiling = on;
     }
     void profile_collect() {
+        flush_record();
         if (recs.empty()) return;
         TEDD_HIP(hipStreamSynchronize(stream));
         for (Rec& r : recs) {
@@ -689,6 +844,14 @@ struct HipBackend {
     void nodes(int fam, const F& f, int r0, int r1, int ncols) {
         check_range(r0, r1, ncols);
         if (r1 == r0) return;
+        if (rec_on) {
+            constexpr int kind = IndexOf<F, PNodeList<REACT_REG>>::value;
+            if constexpr (kind >= 0) {
+                rec_functor(rec_push(PO_NODES, kind, 1, r0, r1, ncols), f);
+                return;
+            }
+            flush_record();
+        }
         Scope sc(this, fam);
         if constexpr (Marches<F>::value) {
             const long long n = (long long)(r1 - r0) * ncols;
@@ -734,6 +897,10 @@ struct HipBackend {
     void forcing(int fam, const F& f, int r0, int r1, int ncols) {
         check_range(r0, r1, ncols);
         if (r1 == r0) return;
+        if (rec_on) {  // (recorded or not, as any node functor)
+            nodes(fam, f, r0, r1, ncols);
+            return;
+        }
         const int tiles_x = (ncols + 255) / 256;
         int seg = 32;
         while (seg > 1 && (long long)tiles_x * ((r1 - r0 + seg - 1) / seg) < 16LL * num_cus) seg /= 2;
@@ -755,6 +922,7 @@ struct HipBackend {
         if (r1 == r0) return;
         if (n_regs < 3 || n_regs > kProgMaxRegs) throw std::runtime_error("bad program register count");
         if (r1 - r0 > 65535) throw std::runtime_error("slab too tall for the program launch");
+        flush_record();
         Scope sc(this, fam);
         dim3 block(64, 1), grid((ncols + 63) / 64, r1 - r0);
         hipLaunchKernelGGL(k_nodes_prog<F>, grid, block, (size_t)n_regs * 64 * sizeof(double), stream, f, r0, r1, ncols);
@@ -771,6 +939,16 @@ struct HipBackend {
     void nodes_max(int fam, const F& f, int r0, int r1, int ncols, double* dev_out) {
         check_range(r0, r1, ncols);
         if (r1 == r0) return;
+        if (rec_on) {
+            constexpr int kind = IndexOf<F, PMaxList<REACT_REG>>::value;
+            if constexpr (kind >= 0) {
+                PDesc& d = rec_push(PO_MAX, kind, 1, r0, r1, ncols);
+                d.out = dev_out;
+                rec_functor(d, f);
+                return;
+            }
+            flush_record();
+        }
         Scope sc(this, fam);
         int tx, nt, nb;
         tiling(r0, r1, ncols, tx, nt, nb);
@@ -781,13 +959,32 @@ struct HipBackend {
     template <class F>
     void nodes_sum(int fam, const F& f, int r0, int r1, int ncols, double* dev_out) {
         check_range(r0, r1, ncols);
-        Scope sc(this, fam);
         if (r1 == r0) {
             memset0(dev_out, F::NR * sizeof(double));
             return;
         }
         int tx, nt, nb;
         tiling(r0, r1, ncols, tx, nt, nb);
+        if (rec_on) {
+            constexpr int kind = IndexOf<F, PSumList>::value;
+            if constexpr (kind >= 0) {
+                PDesc& d = rec_push(PO_SUM, kind, 1, r0, r1, ncols);
+                d.tiles_x = tx;
+                d.ntiles = nt;
+                d.nb = nb;
+                d.nr = F::NR;
+                d.out = d_partials;
+                rec_functor(d, f);
+                PDesc& e = rec_push(PO_SUM_FINAL, 0, 1, 0, 0, 0);
+                e.nb = nb;
+                e.nr = F::NR;
+                e.out = dev_out;
+                e.out2 = d_partials;
+                return;
+            }
+            flush_record();
+        }
+        Scope sc(this, fam);
         hipLaunchKernelGGL(k_nodes_sum<F>, dim3(nb), dim3(kTileX, kTileY), 0, stream, f, r0, r1, ncols, tx, nt, d_partials);
         hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64, F::NR), 0, stream, d_partials, nb, (int)F::NR, dev_out);
         TEDD_HIP(hipGetLastError());
@@ -802,6 +999,7 @@ struct HipBackend {
         static_assert(F::NR <= kScratchSums, "scratch holds at most kScratchSums sums per workgroup");
         check_range(r0, r1, ncols);
         if (!d_scratch) throw std::runtime_error("static scratch address not initialised");
+        flush_record();
         if (r1 == r0) {
             TEDD_HIP(hipMemsetAsync(dev_out, 0, F::NR * sizeof(double), stream));
             return;
@@ -850,6 +1048,7 @@ struct HipBackend {
     template <int VAR, int REACT, bool LAST>
     void solve_strip(int fam, StripArgs A, int ncols, int shape = -1) {
         if (A.r1 <= A.r0) return;
+        flush_record();
         if (A.H < 0 || A.H > 16 || A.nsweeps < 0 || A.nsweeps > A.H) throw std::runtime_error("bad strip-solve depth");
         const bool fused = (A.Y != nullptr);
         if (!fused && (A.b_in == nullptr || (A.d_in == nullptr && A.u_prev == nullptr)))
@@ -913,6 +1112,28 @@ struct HipBackend {
             CorrectClosedFn<CASE, REACT> f{a, cp_out, cs_out, d_keep + 1};
             nodes(FAM_CORRECT, f, r0, r1, ncols);
         } else {
+            if (rec_on) {
+                // (the record must hold its initial values: the prologue of the step saw to it)
+                if (std::is_same<CorrectIn<CASE, REACT>, CorrectIn<CASE_STREAM, REACT_REG>>::value && iters <= kPCsRegs &&
+                    cs_record_clean >= iters && !reduce_hook) {
+                    PDesc& d = rec_push(PO_CS_RECORD, 0, 1, r0, r1, ncols);
+                    d.iters = iters;
+                    d.rtol = rtol;
+                    d.out = cp_out;
+                    d.out2 = cs_out;
+                    rec_functor(d, a);
+                    PDesc& e = rec_push(PO_CS_DECIDE, 0, 1, r0, r1, ncols);
+                    e.iters = iters;
+                    e.rtol = rtol;
+                    e.out = cp_out;
+                    e.out2 = cs_out;
+                    e.keep = d_keep;
+                    rec_functor(e, a);
+                    cs_record_clean = 0;
+                    return;
+                }
+                flush_record();
+            }
             Scope sc(this, FAM_CS_NEWTON);
             int tx, nt, nb;
             tiling(r0, r1, ncols, tx, nt, nb);

@@ -16,6 +16,10 @@ namespace tedd {
 
 struct CpuBackend {
     static constexpr bool kHasStripSolve = false;
+    static constexpr bool kHasPersist = false;
+    void rec_begin(int, int) {}
+    void rec_end() {}
+    void rec_discard() noexcept {}
     double fam_ms[FAM_COUNT] = {0};
     long long fam_n[FAM_COUNT] = {0};
     tedd_reduce_fn reduce_hook = nullptr;
