@@ -67,22 +67,6 @@ __global__ void __launch_bounds__(256) k_copy_rows(double* dst, size_t dpitch, c
         if (j < width) dst[(size_t)i * dpitch + j] = src[(size_t)i * spitch + j];
 }
 
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double o = __shfl_xor(v, off, 64);
-        v = (o > v || o != o) ? o : v;
-    }
-    return v;
-}
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double o = __shfl_xor(v, off, 64);
-        v = (o < v) ? o : v;
-    }
-    return v;
-}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -105,14 +89,13 @@ __global__ void __launch_bounds__(256) k_nodes_max(const F f, int r0, int r1, in
     const int wave = threadIdx.y, lane = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < F::NR; ++k) {
-        const double v = wave_max(red[k]);
+        const double v = wave_max_nan_inf(red[k]);
         if (lane == 0) sm[wave][k] = v;
     }
     __syncthreads();
     if (wave == 0 && lane < F::NR) {
         double v = sm[0][lane];
-        for (int w = 1; w < 4; ++w) v = (sm[w][lane] > v || sm[w][lane] != sm[w][lane]) ? sm[w][lane] : v;
-        if (v != v) v = INFINITY;
+        for (int w = 1; w < 4; ++w) v = sm[w][lane] > v ? sm[w][lane] : v;
         atomicMax(out + lane, (unsigned long long)__double_as_longlong(v));
     }
 }
@@ -233,6 +216,7 @@ __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_R
     __shared__ int keep_sm;
     const int tid = threadIdx.y * kTileX + threadIdx.x;
     int keep = iters;
+    TEDD_STAMP(0);
     if (!record) {
         // second pass: every workgroup reads the decision off the record of the first; the iteration is
         // redone only if the global test stopped it early
@@ -250,6 +234,13 @@ __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_R
             sm[iters + k] = 0x7FF0000000000000ull;
         }
         __syncthreads();
+    }
+    // The record words thread `tid` may move at the end of the record pass, read now: a workgroup that does not
+    // move them then knows so without a round trip at its very end (a value read too early only costs an atomic).
+    unsigned long long seen_mx = 0ull, seen_mn = 0xFFFFFFFFFFFFFFFFull;
+    if (record && tid < iters) {
+        seen_mx = __atomic_load_n(gmax + tid, __ATOMIC_RELAXED);
+        seen_mn = __atomic_load_n(gmin + tid, __ATOMIC_RELAXED);
     }
     // per-thread record of the first kCsReg iterations (the usual case: 5), reduced once at the end
     constexpr int kCsReg = 8;
@@ -272,6 +263,8 @@ __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_R
         int j0, li0;
         if (blockIdx.x < ntiles && place(blockIdx.x, j0, li0)) nxt = cs_node_load(a, at(a.g, li0, j0));
     }
+    TEDD_STAMP_WAIT();
+    TEDD_STAMP(1);
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         int j, li;
         const bool active = place(t, j, li);
@@ -318,7 +311,7 @@ __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_R
                     if (ax != ax) ax = 0.0;
                 }
                 if (record) {
-                    const double wmx = wave_max(adx), wmn = wave_min(ax);
+                    const double wmx = wave_max_nn(adx), wmn = wave_min_nn(ax);  // (NaN replaced above)
                     if (threadIdx.x == 0) {
                         atomicMax(&sm[k], (unsigned long long)__double_as_longlong(wmx));
                         atomicMin(&sm[iters + k], (unsigned long long)__double_as_longlong(wmn));
@@ -328,11 +321,12 @@ __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_R
         }
         if (active) put_once(cs_out + c, in ? x : 0.0 * x);
     }
+    TEDD_STAMP(2);
     if (record && in_regs) {
 #pragma unroll
         for (int k = 0; k < kCsReg; ++k) {
             if (k < iters) {
-                const double wmx = wave_max(rmx[k]), wmn = wave_min(rmn[k]);
+                const double wmx = wave_max_nn(rmx[k]), wmn = wave_min_nn(rmn[k]);  // (no NaN among them: replaced per node)
                 if (threadIdx.x == 0) {
                     atomicMax(&sm[k], (unsigned long long)__double_as_longlong(wmx));
                     atomicMin(&sm[iters + k], (unsigned long long)__double_as_longlong(wmn));
@@ -340,13 +334,17 @@ __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_R
             }
         }
     }
+    TEDD_STAMP(3);
     if (record) {
         __syncthreads();
+        TEDD_STAMP(4);
         for (int k = tid; k < iters; k += 256) {
-            atomicMax(gmax + k, sm[k]);
-            atomicMin(gmin + k, sm[iters + k]);
+            if (k != tid || sm[k] > seen_mx) atomicMax(gmax + k, sm[k]);
+            if (k != tid || sm[iters + k] < seen_mn) atomicMin(gmin + k, sm[iters + k]);
         }
     }
+    TEDD_STAMP_WAIT();
+    TEDD_STAMP(5);
 }
 __global__ void k_cs_decide(const unsigned long long* gmax, const unsigned long long* gmin, int iters, double rtol,
                             int* out_keep) {
@@ -1024,15 +1022,20 @@ struct HipBackend {
             const int TIR = strip_tile_rows(sh) - 2 * H;
             return tiles_x * ((r1 - r0 + TIR - 1) / TIR);
         };
-        const bool small_fits = strip_tile_rows(SHAPE_SMALL) - 2 * H >= 8;
-        const bool mid_fits = strip_tile_rows(SHAPE_MID) - 2 * H >= 8;
+        auto fits = [&](int sh) { return strip_tile_rows(sh) - 2 * H >= (sh == SHAPE_TINY ? 6 : 8); };
         if (shape < 0) {
-            if (small_fits && n_tiles(SHAPE_LARGE) < 2LL * num_cus)
+            if (fits(SHAPE_SMALL) && n_tiles(SHAPE_LARGE) < 2LL * num_cus) {
+                // too few tiles to fill the chip: the latency of one tile is the run time
                 shape = SHAPE_SMALL;
-            else
+                // ... and compute units to spare: two rows per thread (cl, cd)
+                if (var != VAR_T && fits(SHAPE_TINY) && n_tiles(SHAPE_TINY) <= num_cus) shape = SHAPE_TINY;
+            } else {
                 shape = (var != VAR_T && H <= 8) ? SHAPE_MID : SHAPE_LARGE;
+            }
         }
-        if ((shape == SHAPE_SMALL && !small_fits) || (shape == SHAPE_MID && !mid_fits)) shape = SHAPE_LARGE;
+        if (shape == SHAPE_TINY && (var == VAR_T || !fits(SHAPE_TINY))) shape = SHAPE_SMALL;  // (built for cl and cd only)
+        if (shape == SHAPE_SMALL && !fits(SHAPE_SMALL)) shape = SHAPE_LARGE;
+        if (shape == SHAPE_MID && !fits(SHAPE_MID)) shape = SHAPE_LARGE;
         return shape;
     }
     // a single-launch chain of the cl or cd system on 4-row strips can evaluate its right-hand side itself
@@ -1097,6 +1100,8 @@ struct HipBackend {
         };
         if (shape == SHAPE_SMALL)
             by_fused(std::integral_constant<int, SHAPE_SMALL>{});
+        else if (shape == SHAPE_TINY)
+            by_fused(std::integral_constant<int, (VAR == VAR_T) ? SHAPE_SMALL : SHAPE_TINY>{});
         else if (shape == SHAPE_MID)
             by_fused(std::integral_constant<int, SHAPE_MID>{});
         else

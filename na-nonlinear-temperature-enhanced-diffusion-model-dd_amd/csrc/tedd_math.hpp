@@ -20,6 +20,12 @@
 #define TEDD_HD inline
 #endif
 
+// Diagnostic builds only (the stamp tools under tools/ define these): time stamps of a wave's progress.
+#ifndef TEDD_STAMP
+#define TEDD_STAMP(i)
+#define TEDD_STAMP_WAIT()
+#endif
+
 namespace tedd {
 
 // CASE_PROG is a run-time case (expression programs, tedd_prog.hpp); the kernels templated on a case

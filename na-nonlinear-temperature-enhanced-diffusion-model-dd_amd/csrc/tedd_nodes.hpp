@@ -205,6 +205,7 @@ struct PredictFn {
             // array-fed forcing: everything the node reads is requested at once, whatever kind of node it is
             // (on a small mesh the launch is as long as its longest chain of dependent loads), then the
             // arithmetic of the marching launcher's node body
+            TEDD_STAMP(0);
             const St5 cp = load5_clamped(S.v[VAR_CP], g, li, j), T = load5_clamped(S.v[VAR_T], g, li, j);
             const St5 cl = load5_clamped(S.v[VAR_CL], g, li, j), cd = load5_clamped(S.v[VAR_CD], g, li, j);
             const double cs0 = S.v[VAR_CS][c];
@@ -218,6 +219,8 @@ struct PredictFn {
             }
             const Geo ge = geo_at_clamped(g, li, j);
             loads_done();
+            TEDD_STAMP_WAIT();
+            TEDD_STAMP(1);
             if (FCASE != CASE_STREAM) {
                 const Forcing5 fb = node_forcing<FCASE, REACT>(m, tb, f1, g, li, j, in, true);
                 fcp1 = fb.fcp;
@@ -229,10 +232,16 @@ struct PredictFn {
                 put_once(f1_out.v[3] + c, fb.fcd);
                 put_once(f1_out.v[4] + c, fb.fcs);
             }
+            TEDD_STAMP_WAIT();
+            TEDD_STAMP(2);
             const F5 F = node_field_vals<REACT>(m, ge, cp, T, cl, cd, cs0, fa, in);
             St5 Tb{T.c, 0.0, 0.0, 0.0, 0.0};
             if (bT && in) Tb = T;
+            TEDD_STAMP(3);
             finish(c, in, ge, F, fa, cp.c, Tb, cl.c, cd.c, cs0, fcp1, fcs1, fT1);
+            TEDD_STAMP(4);
+            TEDD_STAMP_WAIT();
+            TEDD_STAMP(5);
             return;
         }
         Forcing5 fa = node_forcing<CASE, REACT>(m, tb, f0, g, li, j, in, fcp_t0 == nullptr);

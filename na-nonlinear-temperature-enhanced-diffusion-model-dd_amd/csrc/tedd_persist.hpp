@@ -128,22 +128,6 @@ __device__ __forceinline__ bool p_grid_barrier(const PersistCtl& c, unsigned& pa
     return *sh_abort == 0;
 }
 
-__device__ __forceinline__ double p_wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double o = __shfl_xor(v, off, 64);
-        v = (o > v || o != o) ? o : v;
-    }
-    return v;
-}
-__device__ __forceinline__ double p_wave_min(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double o = __shfl_xor(v, off, 64);
-        v = (o < v) ? o : v;
-    }
-    return v;
-}
 __device__ __forceinline__ double p_wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -176,7 +160,7 @@ __device__ __forceinline__ void p_max(const PDesc& d) {
     }
 #pragma unroll
     for (int k = 0; k < F::NR; ++k) {
-        const double v = p_wave_max(red[k]);
+        const double v = wave_max_nan_inf(red[k]);
         if (threadIdx.x == 0) p_raise(reinterpret_cast<unsigned long long*>(d.out) + k, v);
     }
 }
@@ -280,7 +264,7 @@ __device__ __forceinline__ void p_cs(const PDesc& d, const PersistCtl& c, bool r
 #pragma unroll
         for (int k = 0; k < kPCsRegs; ++k) {
             if (k < iters) {
-                const double wmx = p_wave_max(rmx[k]), wmn = p_wave_min(rmn[k]);
+                const double wmx = wave_max_nn(rmx[k]), wmn = wave_min_nn(rmn[k]);
                 if (threadIdx.x == 0) {
                     p_raise(c.gmax + k, wmx);
                     p_lower(c.gmin + k, wmn);

@@ -37,6 +37,7 @@ namespace tedd {
 
 constexpr int kSTile = 64;  // tile width (nodes = lanes), halo included
 
+
 // SHAPE_LARGE: 4 waves x 16 rows (64-row tiles): least halo overhead per node; the T system on large
 //   meshes (deep chains of 10 sweeps, lean rows that fit 4 waves per SIMD).
 // SHAPE_MID: 12 waves x 4 rows (48-row tiles): a quarter of the registers per thread, so 6 waves per SIMD
@@ -45,12 +46,18 @@ constexpr int kSTile = 64;  // tile width (nodes = lanes), halo included
 // SHAPE_SMALL: 8 waves x 4 rows (32-row tiles): meshes with too few large tiles to occupy the compute
 //   units, where the latency of one tile is the run time (a quarter of the set-up and sweep work per wave,
 //   more and smaller workgroups): 9.6k -> 14.7k steps/s at 256^2.
+// SHAPE_TINY: 8 waves x 2 rows (16-row tiles), cl and cd systems on meshes with fewer small tiles than compute
+//   units.  What a launch takes there is the chain of one thread (its loads, the faces and rows it sets up, its
+//   share of every sweep): two rows per thread instead of four shorten it, on twice as many compute units
+//   (256^2, in-kernel time of the cd launch with its right-hand side 11.7 -> 7.9 us, cl 8.9 -> 6.5).  The T
+//   system keeps the 32-row tiles: its deep chains leave no interior in a 16-row tile, and its time is the
+//   per-sweep exchange (0.37 us a sweep, the same with 16 waves x 2 rows: measured, 8.2 -> 8.7 us).
 // All shapes perform the same arithmetic on every node they write: results do not depend on the shape.
-enum : int { SHAPE_LARGE = 0, SHAPE_SMALL = 1, SHAPE_MID = 2 };
+enum : int { SHAPE_LARGE = 0, SHAPE_SMALL = 1, SHAPE_MID = 2, SHAPE_TINY = 3 };
 
 template <int VAR, int SHAPE>
 struct StripShape {
-    static constexpr int R = (SHAPE == SHAPE_LARGE) ? 16 : 4;  // rows per thread
+    static constexpr int R = (SHAPE == SHAPE_LARGE) ? 16 : (SHAPE == SHAPE_TINY) ? 2 : 4;  // rows per thread
     static constexpr int W = (SHAPE == SHAPE_LARGE) ? 4 : (SHAPE == SHAPE_MID) ? 12 : 8;  // waves per workgroup
     static constexpr int TR = R * W;                            // tile height (nodes), halo included
     // waves per SIMD the register budget is set for
@@ -58,7 +65,9 @@ struct StripShape {
     // ... with the right-hand side fused in (more live columns during the set-up)
     static constexpr int OCC_FUSED = (SHAPE == SHAPE_MID) ? 3 : (VAR == VAR_CD) ? 2 : 3;
 };
-__host__ __device__ inline int strip_tile_rows(int shape) { return shape == SHAPE_SMALL ? 32 : shape == SHAPE_MID ? 48 : 64; }
+__host__ __device__ inline int strip_tile_rows(int shape) {
+    return shape == SHAPE_TINY ? 16 : shape == SHAPE_SMALL ? 32 : shape == SHAPE_MID ? 48 : 64;
+}
 
 // column halo of a launch of depth H: H rounded up to even, so that the row segments a wave reads and
 // the interior it writes stay 16-byte aligned.  (A fixed 8-node halo would keep them on 64-byte lines,
@@ -89,6 +98,43 @@ __device__ __forceinline__ double lane_above(double v) {
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+// Maximum / minimum over the 64 lanes of a wave, for values that are not NaN, returned in every lane.  Six
+// steps of lane moves inside the vector unit (DPP: the pairs of a quad, the quads of 8 lanes, the halves of a
+// row of 16, then lane 15 and lane 31 into the rows above) with one v_max_f64 / v_min_f64 each: about 20
+// instructions and no LDS traffic.  The same reduction as a butterfly of __shfl_xor costs six dependent trips
+// through the LDS crossbar with NaN-aware selects around them: ten of those at the end of the cs corrector's
+// record pass took 3.9 of its 9.8 microseconds on a 256^2 mesh.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);  // (lanes the row mask leaves out keep v)
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane63_f64(double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ double wave_max_nn(double v) {
+    v = fmax(v, dpp_move_f64<0xB1, 0xf>(v));   // quad_perm [1,0,3,2]
+    v = fmax(v, dpp_move_f64<0x4E, 0xf>(v));   // quad_perm [2,3,0,1]
+    v = fmax(v, dpp_move_f64<0x141, 0xf>(v));  // row_half_mirror
+    v = fmax(v, dpp_move_f64<0x140, 0xf>(v));  // row_mirror
+    v = fmax(v, dpp_move_f64<0x142, 0xa>(v));  // row_bcast:15 into rows 1 and 3
+    v = fmax(v, dpp_move_f64<0x143, 0xc>(v));  // row_bcast:31 into rows 2 and 3
+    return lane63_f64(v);
+}
+__device__ __forceinline__ double wave_min_nn(double v) {
+    v = fmin(v, dpp_move_f64<0xB1, 0xf>(v));
+    v = fmin(v, dpp_move_f64<0x4E, 0xf>(v));
+    v = fmin(v, dpp_move_f64<0x141, 0xf>(v));
+    v = fmin(v, dpp_move_f64<0x140, 0xf>(v));
+    v = fmin(v, dpp_move_f64<0x142, 0xa>(v));
+    v = fmin(v, dpp_move_f64<0x143, 0xc>(v));
+    return lane63_f64(v);
+}
+// ... with a NaN anywhere reported as +inf (what every record of a maximum stores for it)
+__device__ __forceinline__ double wave_max_nan_inf(double v) { return wave_max_nn(v != v ? INFINITY : v); }
+
 // WARM: first launch of a warm-started chain (StripArgs::u_prev, gscale, stats_first); a separate
 // instantiation so that the launches from zero iterates carry none of its registers and branches.
 // FUSED (cl and cd systems, the only launch of a chain, 4-row strips): the launch evaluates the right-hand
@@ -108,11 +154,12 @@ k_solve_strip(const StripArgs A) {
     constexpr int R = StripShape<VAR, SHAPE>::R, W = StripShape<VAR, SHAPE>::W, TR = StripShape<VAR, SHAPE>::TR;
     constexpr bool LEAN = (VAR == VAR_T);
     constexpr int kBatch = (R > 4) ? 4 : R;  // rows whose late loads (warm iterate, lagged unknown) are in flight together
-    static_assert(!FUSED || (LAST && !LEAN && R == 4), "fused right-hand side: last launch of a cl/cd chain, 4-row strips");
+    static_assert(!FUSED || (LAST && !LEAN && R <= 4), "fused right-hand side: last launch of a cl/cd chain, short strips");
     __shared__ double seam[2][W][2][kSTile];  // [parity][wave][first/last row of the strip][lane]
     __shared__ double2 rowc[LEAN ? TR : 1];  // lean rows: (dt J_e, dt J_w) of each tile row
     const int lane = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    TEDD_STAMP(0);
     const GridDev& g = A.g;
     const ModelC& m = A.m;
     // (fused right-hand side: b at the two end lanes of the wave lacks a column neighbour, so the column
@@ -156,10 +203,20 @@ k_solve_strip(const StripArgs A) {
     // array and (cd) the new cl at the thread's own rows
     double uov[FUSED ? R + 2 : 1], Tnv[FUSED ? R + 2 : 1], Yv[FUSED ? R : 1], fvv[FUSED ? R : 1];
     double clnv[(FUSED && VAR == VAR_CD) ? R : 1];
+    // Short strips of the T system keep the lagged unknown from here on (4 values) instead of asking for it
+    // at the write-back, where nothing else is left to hide that round trip behind.
+    constexpr bool UOLD_EARLY = LAST && LEAN && R <= 4 && !FUSED;
+    double uold_e[UOLD_EARLY ? R : 1];
+    // The record words this launch may raise at its very end, read now: most tiles find at the end that they do
+    // not raise them, without a round trip there (a value read too early is too small: one atomic more, never
+    // one fewer).
+    unsigned long long stat_seen = 0ull;
+    if (LAST) stat_seen = __atomic_load_n(A.stats + (lane & 1), __ATOMIC_RELAXED);
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const size_t c = (size_t)min(max(row0 + k, 0), rmax) * g.ld + jc;
         if (!FUSED) b[k] = A.b_in[c];
+        if (UOLD_EARLY) uold_e[k] = A.a.To[c];
         if (LEAN && !WARM) d[k] = A.d_in[c];  // (the same line as b[k] in the first launch of a cold chain)
         if (VAR == VAR_CD) {
             clv[k] = A.a.clo[c];
@@ -183,6 +240,8 @@ k_solve_strip(const StripArgs A) {
         }
     }
     const double rks = g.rk[jc], rkn = g.rk[min(jc + 1, g.ncols - 1)], rkm = g.rkm[jc];
+    TEDD_STAMP_WAIT();
+    TEDD_STAMP(1);
 
     // ---- matrix rows
     // full rows (cl, cd): ce..cs scaled by 1/diag.  Every face coefficient is evaluated once, by the
@@ -193,6 +252,10 @@ k_solve_strip(const StripArgs A) {
     double ce[LEAN ? 1 : R], cw[LEAN ? 1 : R], cn[LEAN ? 1 : R], cs[LEAN ? 1 : R];
     double inv[LEAN ? R : 1];
     double on = 0.0, os = 0.0;
+    // (short strips keep the per-row off-diagonals of the T system in registers too: the LDS read they replace
+    // stands at the head of every node's update)
+    constexpr bool ROWC_REGS = LEAN && R <= 4;
+    double rce[ROWC_REGS ? R : 1], rcw[ROWC_REGS ? R : 1];
     constexpr bool EXACT = FUSED || XFACE;
     constexpr int NF = LEAN ? 1 : 2 * R + 1;       // [0..R] x faces (between rows k-1 and k), [R+1..2R] y faces of row k
     constexpr bool WANT_DT = FUSED && VAR == VAR_CD;  // dDd/dT on the faces (coupling with the new T)
@@ -262,7 +325,7 @@ k_solve_strip(const StripArgs A) {
     };
     // (short strips: the row metrics of all R rows are requested together, ahead of the loop that uses them
     // one row at a time)
-    constexpr bool GEO_AHEAD = (R == 4);
+    constexpr bool GEO_AHEAD = (R <= 4);
     double rhv[GEO_AHEAD ? R + 1 : 1], rhmv[GEO_AHEAD ? R : 1];
     if (GEO_AHEAD) {
 #pragma unroll
@@ -284,7 +347,12 @@ k_solve_strip(const StripArgs A) {
             r = jac_T_FT(m, ge, cpv[k + 1]);
             const double iv = tedd_div(1.0, 2.0 - A.dt * r.c);
             inv[k] = active ? iv : 0.0;
-            if (lane == 0) rowc[R * wave + k] = make_double2(A.dt * r.e, A.dt * r.w);  // read back by this wave only
+            if (ROWC_REGS) {
+                rce[ROWC_REGS ? k : 0] = A.dt * r.e;
+                rcw[ROWC_REGS ? k : 0] = A.dt * r.w;
+            } else if (lane == 0) {
+                rowc[R * wave + k] = make_double2(A.dt * r.e, A.dt * r.w);  // read back by this wave only
+            }
             on = A.dt * r.n;
             os = A.dt * r.s;
         } else {
@@ -372,6 +440,8 @@ k_solve_strip(const StripArgs A) {
         for (int k = 0; k < R; ++k) d[k] = is_active(row0 + k) ? d[k] : 0.0;
     }
 
+    TEDD_STAMP_WAIT();
+    TEDD_STAMP(2);
     // which of this thread's nodes are written back
     const bool lane_in = (lane >= HC && lane < kSTile - HC && j >= 0 && j < g.ncols);
     double up_max = 0.0, mag_max = 0.0;
@@ -391,7 +461,7 @@ k_solve_strip(const StripArgs A) {
     // differs between instantiations of the kernel, and the tile shapes would no longer agree bit for bit)
     auto update = [&](int k, double prev, double cur, double nxt) {
         if (LEAN) {
-            const double2 rc = rowc[R * wave + k];
+            const double2 rc = ROWC_REGS ? make_double2(rce[ROWC_REGS ? k : 0], rcw[ROWC_REGS ? k : 0]) : rowc[R * wave + k];
             double acc = rc.y * prev;
             acc = fma(rc.x, nxt, acc);
             acc = fma(on, lane_above(cur), acc);
@@ -408,7 +478,7 @@ k_solve_strip(const StripArgs A) {
     // the lagged unknown between its update and its store, one memory round trip per row.
     // (full rows of 16 nodes have no registers for a second copy of the sweep: their final sweep stays in the
     // loop, told apart by a flag)
-    constexpr bool PEEL_FINAL = LAST && (LEAN || R == 4);
+    constexpr bool PEEL_FINAL = LAST && (LEAN || R <= 4);
     const int plain_end = PEEL_FINAL ? max(A.nsweeps - 1, 0) : A.nsweeps;
     int sw0 = 1;
     if (WARM && plain_end >= 1) {
@@ -428,13 +498,8 @@ k_solve_strip(const StripArgs A) {
             first_max = (up > first_max || up != up) ? up : first_max;
             prev = cur;
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double o = __shfl_xor(first_max, off, 64);
-            first_max = (o > first_max || o != o) ? o : first_max;
-        }
+        first_max = wave_max_nan_inf(first_max);
         if (lane == 0) {
-            if (first_max != first_max) first_max = INFINITY;
             const unsigned long long bits = (unsigned long long)__double_as_longlong(first_max);
             if (bits > __atomic_load_n(A.stats_first, __ATOMIC_RELAXED)) atomicMax(A.stats_first, bits);
         }
@@ -474,6 +539,7 @@ k_solve_strip(const StripArgs A) {
         }
     }
 
+    TEDD_STAMP(3);
     // ---- write back the tile interior.  The coordinates are laundered through empty asm so that
     // the store addresses are rebuilt here instead of being kept in registers across the sweeps.
     const double* uo = (VAR == VAR_T) ? A.a.To : (VAR == VAR_CL) ? A.a.clo : A.a.cdo;
@@ -489,6 +555,8 @@ k_solve_strip(const StripArgs A) {
             for (int k = k0; k < k0 + kBatch; ++k) {
                 if (FUSED)
                     uold[k - k0] = uov[FUSED ? k + 1 : 0];
+                else if (UOLD_EARLY)
+                    uold[k - k0] = uold_e[UOLD_EARLY ? k : 0];
                 else
                     uold[k - k0] = uo[(size_t)min(max(row0w + k, 0), rmax) * g.ld + min(max(jw, 0), g.ncols - 1)];
             }
@@ -518,15 +586,12 @@ k_solve_strip(const StripArgs A) {
             if (r >= H && r < TR - H && li >= A.r0 && li < A.r1 && lane_in) A.d_out[at(g, li, jw)] = d[k];
         }
     }
+    TEDD_STAMP(4);
     if (LAST) {
         __syncthreads();  // the seam rows are dead: reuse their first doubles
         double* red = &seam[0][0][0][0];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double o1 = __shfl_xor(up_max, off, 64), o2 = __shfl_xor(mag_max, off, 64);
-            up_max = (o1 > up_max || o1 != o1) ? o1 : up_max;
-            mag_max = (o2 > mag_max || o2 != o2) ? o2 : mag_max;
-        }
+        up_max = wave_max_nan_inf(up_max);
+        mag_max = wave_max_nan_inf(mag_max);
         if (lane == 0) {
             red[2 * wave] = up_max;
             red[2 * wave + 1] = mag_max;
@@ -541,9 +606,11 @@ k_solve_strip(const StripArgs A) {
             if (v != v) v = INFINITY;
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
             // most tiles do not raise the maximum: skip their atomics
-            if (bits > __atomic_load_n(A.stats + lane, __ATOMIC_RELAXED)) atomicMax(A.stats + lane, bits);
+            if (bits > stat_seen) atomicMax(A.stats + lane, bits);
         }
     }
+    TEDD_STAMP_WAIT();
+    TEDD_STAMP(5);
 }
 
 }  // namespace tedd
