@@ -322,25 +322,46 @@ __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_R
         if (active) put_once(cs_out + c, in ? x : 0.0 * x);
     }
     TEDD_STAMP(2);
+    // The record of the usual case leaves the workgroup through plain LDS words, one set per wave (lane k keeps
+    // the wave's values of iteration k), combined by thread k after the barrier: no LDS atomics.
+    __shared__ unsigned long long wrec[kTileY][2 * kCsReg];
     if (record && in_regs) {
+        double mine_mx = 0.0, mine_mn = INFINITY;
 #pragma unroll
         for (int k = 0; k < kCsReg; ++k) {
             if (k < iters) {
                 const double wmx = wave_max_nn(rmx[k]), wmn = wave_min_nn(rmn[k]);  // (no NaN among them: replaced per node)
-                if (threadIdx.x == 0) {
-                    atomicMax(&sm[k], (unsigned long long)__double_as_longlong(wmx));
-                    atomicMin(&sm[iters + k], (unsigned long long)__double_as_longlong(wmn));
+                if ((int)threadIdx.x == k) {
+                    mine_mx = wmx;
+                    mine_mn = wmn;
                 }
             }
+        }
+        if ((int)threadIdx.x < iters) {
+            wrec[threadIdx.y][threadIdx.x] = (unsigned long long)__double_as_longlong(mine_mx);
+            wrec[threadIdx.y][kCsReg + threadIdx.x] = (unsigned long long)__double_as_longlong(mine_mn);
         }
     }
     TEDD_STAMP(3);
     if (record) {
         __syncthreads();
         TEDD_STAMP(4);
-        for (int k = tid; k < iters; k += 256) {
-            if (k != tid || sm[k] > seen_mx) atomicMax(gmax + k, sm[k]);
-            if (k != tid || sm[iters + k] < seen_mn) atomicMin(gmin + k, sm[iters + k]);
+        if (in_regs) {
+            if (tid < iters) {
+                unsigned long long mx = wrec[0][tid], mn = wrec[0][kCsReg + tid];
+#pragma unroll
+                for (int w = 1; w < kTileY; ++w) {
+                    mx = wrec[w][tid] > mx ? wrec[w][tid] : mx;
+                    mn = wrec[w][kCsReg + tid] < mn ? wrec[w][kCsReg + tid] : mn;
+                }
+                if (mx > seen_mx) atomicMax(gmax + tid, mx);
+                if (mn < seen_mn) atomicMin(gmin + tid, mn);
+            }
+        } else {
+            for (int k = tid; k < iters; k += 256) {
+                if (k != tid || sm[k] > seen_mx) atomicMax(gmax + k, sm[k]);
+                if (k != tid || sm[iters + k] < seen_mn) atomicMin(gmin + k, sm[iters + k]);
+            }
         }
     }
     TEDD_STAMP_WAIT();
@@ -1168,8 +1189,12 @@ struct HipBackend {
                 if (reduce_hook(reduce_user, reinterpret_cast<double*>(gmax), reinterpret_cast<double*>(gmin), iters) != 0)
                     throw std::runtime_error("the reduce hook failed (cs corrector record)");
             }
-            if (iters > 1)  // decides by itself whether anything is left to do
-                hipLaunchKernelGGL(k_cs_newton<CASE>, dim3(nb), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx,
+            // The second pass decides by itself whether anything is left to do, which is almost never: on small
+            // meshes it is launched with few workgroups (what it costs is their number: 3.5 us for the 325 of a
+            // 256^2 mesh), each of which walks over 16 tiles in the rare case that it has to iterate again.
+            const int nb2 = (nt <= 4096) ? std::min(nb, std::max(32, nt / 16)) : nb;
+            if (iters > 1)
+                hipLaunchKernelGGL(k_cs_newton<CASE>, dim3(nb2), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx,
                                    nt, cp_out, cs_out, iters, false, rtol, d_keep, gmax, gmin);
             else
                 hipLaunchKernelGGL(k_cs_decide, dim3(1), dim3(1), 0, stream, gmax, gmin, iters, rtol, d_keep);
