@@ -67,12 +67,6 @@ __global__ void __launch_bounds__(256) k_copy_rows(double* dst, size_t dpitch, c
         if (j < width) dst[(size_t)i * dpitch + j] = src[(size_t)i * spitch + j];
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 // max-reduction of non-negative values: grid-stride over 4x64 tiles, one atomic per block and slot
 template <class F>
 __global__ void __launch_bounds__(256) k_nodes_max(const F f, int r0, int r1, int ncols, int tiles_x, int ntiles,
@@ -116,7 +110,7 @@ __global__ void __launch_bounds__(256) k_nodes_sum(const F f, int r0, int r1, in
     const int wave = threadIdx.y, lane = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < F::NR; ++k) {
-        const double v = wave_sum(red[k]);
+        const double v = wave_sum_fixed(red[k]);
         if (lane == 0) sm[wave][k] = v;
     }
     __syncthreads();
@@ -129,7 +123,7 @@ __global__ void k_sum_final(const double* partials, int nblocks, int nr, double*
     const int k = threadIdx.y;
     double s = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * nr + k];
-    s = wave_sum(s);
+    s = wave_sum_fixed(s);
     if (threadIdx.x == 0) out[k] = s;
 }
 

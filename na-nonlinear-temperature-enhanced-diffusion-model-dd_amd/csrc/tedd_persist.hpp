@@ -128,12 +128,6 @@ __device__ __forceinline__ bool p_grid_barrier(const PersistCtl& c, unsigned& pa
     return *sh_abort == 0;
 }
 
-__device__ __forceinline__ double p_wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 // ---- phases
 // plain node functor: the nodes of the row range dealt to the threads of the grid one by one (a row of a small
 // mesh is shorter than a wave, so lanes are not tied to columns)
@@ -188,7 +182,7 @@ __device__ __forceinline__ void p_sum(const PDesc& d, double (*sm)[8]) {
         }
 #pragma unroll
         for (int q = 0; q < F::NR; ++q) {
-            const double v = p_wave_sum(red[q]);
+            const double v = wave_sum_fixed(red[q]);
             if (lane == 0) sm[wave][q] = v;
         }
         __syncthreads();
@@ -204,7 +198,7 @@ __device__ __forceinline__ void p_sum_final(const PDesc& d) {
     const int k = threadIdx.y;
     double s = 0.0;
     for (int b = threadIdx.x; b < d.nb; b += 64) s += d.out2[(size_t)b * d.nr + k];
-    s = p_wave_sum(s);
+    s = wave_sum_fixed(s);
     if (threadIdx.x == 0) d.out[k] = s;
 }
 

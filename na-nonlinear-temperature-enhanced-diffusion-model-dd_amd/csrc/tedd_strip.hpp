@@ -132,6 +132,27 @@ __device__ __forceinline__ double wave_min_nn(double v) {
     v = fmin(v, dpp_move_f64<0x143, 0xc>(v));
     return lane63_f64(v);
 }
+// Sum over the 64 lanes in one fixed order (the same on every run: pairs of a quad, quads of 8 lanes, halves of
+// a row, rows 0+1 and 2+3, then the two halves of the wave), returned in every lane.
+__device__ __forceinline__ double wave_sum_fixed(double v) {
+    v += dpp_move_f64<0xB1, 0xf>(v);
+    v += dpp_move_f64<0x4E, 0xf>(v);
+    v += dpp_move_f64<0x141, 0xf>(v);
+    v += dpp_move_f64<0x140, 0xf>(v);
+    {  // lane 15 of rows 0 and 2 into rows 1 and 3 (the other rows add 0)
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xa, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xa, 0xf, false);
+        v += __hiloint2double(hi, lo);
+    }
+    {  // lane 31 into rows 2 and 3
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xc, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xc, 0xf, false);
+        v += __hiloint2double(hi, lo);
+    }
+    return lane63_f64(v);
+}
 // ... with a NaN anywhere reported as +inf (what every record of a maximum stores for it)
 __device__ __forceinline__ double wave_max_nan_inf(double v) { return wave_max_nn(v != v ? INFINITY : v); }
 
