@@ -109,7 +109,10 @@ public:
     // a warm start reads two more arrays than a start from zero: where the record says it would not save
     // three sweeps or a launch, that system starts from zero until this sequence number (then it is tried again)
     long long cold_until[3] = {0, 0, 0};
-    static constexpr int kColdSpell = 64;
+    // ... for 64 steps after the first such verdict, twice as long after every further one (the steps that try
+    // the warm start again are the dearest of a run on a small mesh: two more arrays and a second launch)
+    static constexpr int kColdSpell = 64, kColdSpellMax = 4096;
+    int cold_spell[3] = {kColdSpell, kColdSpell, kColdSpell};
     double* d_series = nullptr;   // error-norm series of tedd_advance
     size_t series_cap = 0;
     int* d_ints = nullptr;        // [0] cs iterations kept, [1] HCsTriple corrector: denominator not positive
@@ -549,7 +552,10 @@ public:
         release_retained();
         drop_prev();
         chain_start = next_seq;  // records of steps before this point say nothing about the new state
-        for (int v = 0; v < 3; ++v) cold_until[v] = 0;
+        for (int v = 0; v < 3; ++v) {
+            cold_until[v] = 0;
+            cold_spell[v] = kColdSpell;
+        }
     }
     void ensure_state_buffers() {
         for (int v = 0; v < 5; ++v)
@@ -952,7 +958,8 @@ public:
                     const int hmax = std::min(opt_strip_hmax > 0 ? opt_strip_hmax : 10, 16);
                     auto launches = [&](int sweeps_in_chain) { return std::max(1, (sweeps_in_chain + hmax - 1) / hmax); };
                     if (!((cold - 1) - s >= 3 || launches(s) < launches(cold - 1))) {
-                        cold_until[v] = next_seq + kColdSpell;
+                        cold_until[v] = next_seq + cold_spell[v];
+                        cold_spell[v] = std::min(2 * cold_spell[v], (int)kColdSpellMax);
                         warm = false;
                         s = cold;
                     }

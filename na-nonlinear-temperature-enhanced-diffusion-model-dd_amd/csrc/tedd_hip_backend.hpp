@@ -41,11 +41,27 @@ constexpr size_t kScratchDoubles = (size_t)kMaxReduceBlocks * kScratchSums;
 static __device__ __align__(256) double scratch[kScratchDoubles];
 constexpr int kMaxDevices = 64;
 
+// `flat` (a 1-D grid): the nodes of the rows are dealt to the threads one after the other instead of as
+// 64 x 4 tiles.  On a small mesh whose width is just over a multiple of 64 (257 columns: 5 tiles across, the
+// fifth with one live lane) the tiles make a quarter more waves than the nodes fill, each as long as a full
+// one; with 66 049 nodes that is 1300 waves for 1024 SIMDs instead of 1033, and the launch is as long as the
+// SIMDs that hold two.
+__device__ __forceinline__ bool node_of_thread(bool flat, int r0, int r1, int ncols, int& li, int& j) {
+    if (flat) {
+        const int q = blockIdx.x * (kTileX * kTileY) + threadIdx.y * kTileX + threadIdx.x;
+        const int row = q / ncols;
+        li = r0 + row;
+        j = q - row * ncols;
+        return li < r1;
+    }
+    j = blockIdx.x * kTileX + threadIdx.x;
+    li = r0 + blockIdx.y * kTileY + threadIdx.y;
+    return j < ncols && li < r1;
+}
 template <class F>
-__global__ void __launch_bounds__(256) k_nodes(const F f, int r0, int r1, int ncols) {
-    const int j = blockIdx.x * kTileX + threadIdx.x;
-    const int li = r0 + blockIdx.y * kTileY + threadIdx.y;
-    if (j < ncols && li < r1) f(li, j);
+__global__ void __launch_bounds__(256) k_nodes(const F f, int r0, int r1, int ncols, bool flat) {
+    int li, j;
+    if (node_of_thread(flat, r0, r1, ncols, li, j)) f(li, j);
 }
 
 // Node functors that interpret an expression program (tedd_prog.hpp): one wave per workgroup, the
@@ -176,13 +192,12 @@ __global__ void k_step_prologue(const StepRecordArgs a, unsigned long long* gmax
 // Nothing else in the launch, and no launch between this one and the solves, touches the records.
 template <class F>
 __global__ void __launch_bounds__(256) k_nodes_pro(const F f, int r0, int r1, int ncols, const StepRecordArgs a,
-                                                  unsigned long long* gmax, unsigned long long* gmin) {
+                                                  unsigned long long* gmax, unsigned long long* gmin, bool flat) {
     __shared__ double rec[16];
     if (blockIdx.x == 0 && blockIdx.y == 0)
         step_prologue_body(a, gmax, gmin, threadIdx.y * kTileX + threadIdx.x, 256, rec);
-    const int j = blockIdx.x * kTileX + threadIdx.x;
-    const int li = r0 + blockIdx.y * kTileY + threadIdx.y;
-    if (j < ncols && li < r1) f(li, j);
+    int li, j;
+    if (node_of_thread(flat, r0, r1, ncols, li, j)) f(li, j);
 }
 // Forcing arrays by threads that walk down columns: a workgroup covers 256 columns and `seg_rows` rows.  The
 // column's table entries are loaded once into registers; the row's entries have the same address in every
@@ -247,7 +262,15 @@ __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_R
     }
     // a workgroup walks over its tiles; the six values a node reads are requested one tile ahead, so that
     // the iteration of the present tile runs while they travel
+    // (tiles_x == 0: "tiles" are runs of 256 consecutive nodes of the rows, see k_nodes)
     auto place = [&](int t, int& j, int& li) {
+        if (tiles_x == 0) {
+            const int q = t * (kTileX * kTileY) + tid;
+            const int row = q / ncols;
+            li = r0 + row;
+            j = q - row * ncols;
+            return li < r1;
+        }
         j = (t % tiles_x) * kTileX + threadIdx.x;
         li = r0 + (t / tiles_x) * kTileY + threadIdx.y;
         return j < ncols && li < r1;
@@ -673,8 +696,9 @@ struct HipBackend {
             flush_record();
         }
         Scope sc(this, fam);
-        dim3 block(kTileX, kTileY), grid((ncols + kTileX - 1) / kTileX, (r1 - r0 + kTileY - 1) / kTileY);
-        hipLaunchKernelGGL(k_nodes_pro<F>, grid, block, 0, stream, f, r0, r1, ncols, a, d_csstats, d_csstats + 4096);
+        const bool flat = flat_nodes(r0, r1, ncols);
+        dim3 block(kTileX, kTileY), grid = node_grid(flat, r0, r1, ncols);
+        hipLaunchKernelGGL(k_nodes_pro<F>, grid, block, 0, stream, f, r0, r1, ncols, a, d_csstats, d_csstats + 4096, flat);
         TEDD_HIP(hipGetLastError());
         if (a.clear) cs_record_clean = a.cs_iters;
     }
@@ -850,6 +874,16 @@ struct HipBackend {
     }
 
     // ---- launchers
+    // small slabs whose tiles would be more than a tenth empty lanes: nodes dealt to the threads in a row (k_nodes)
+    static bool flat_nodes(int r0, int r1, int ncols) {
+        const long long n = (long long)(r1 - r0) * ncols;
+        const long long tiled = (long long)((ncols + kTileX - 1) / kTileX) * kTileX * (((r1 - r0) + kTileY - 1) / kTileY) * kTileY;
+        return n <= (1LL << 22) && 10 * tiled > 11 * n;
+    }
+    static dim3 node_grid(bool flat, int r0, int r1, int ncols) {
+        if (flat) return dim3((unsigned)(((long long)(r1 - r0) * ncols + kTileX * kTileY - 1) / (kTileX * kTileY)));
+        return dim3((ncols + kTileX - 1) / kTileX, (r1 - r0 + kTileY - 1) / kTileY);
+    }
     static void check_range(int r0, int r1, int ncols) {
         if (r1 < r0 || ncols <= 0) throw std::runtime_error("bad launch range");
     }
@@ -901,8 +935,9 @@ struct HipBackend {
                 return;
             }
         }
-        dim3 block(kTileX, kTileY), grid((ncols + kTileX - 1) / kTileX, (r1 - r0 + kTileY - 1) / kTileY);
-        hipLaunchKernelGGL(k_nodes<F>, grid, block, 0, stream, f, r0, r1, ncols);
+        const bool flat = flat_nodes(r0, r1, ncols);
+        dim3 block(kTileX, kTileY), grid = node_grid(flat, r0, r1, ncols);
+        hipLaunchKernelGGL(k_nodes<F>, grid, block, 0, stream, f, r0, r1, ncols, flat);
         TEDD_HIP(hipGetLastError());
     }
     // the five forcing arrays of a closed-form case (F: ForcingFn)
@@ -1157,6 +1192,11 @@ struct HipBackend {
             Scope sc(this, FAM_CS_NEWTON);
             int tx, nt, nb;
             tiling(r0, r1, ncols, tx, nt, nb);
+            if (flat_nodes(r0, r1, ncols)) {  // (runs of 256 nodes instead of 64 x 4 tiles: see k_nodes)
+                tx = 0;
+                nt = (int)(((long long)(r1 - r0) * ncols + kTileX * kTileY - 1) / (kTileX * kTileY));
+                nb = nt < kMaxReduceBlocks ? nt : kMaxReduceBlocks;
+            }
             unsigned long long* gmax = d_csstats;
             unsigned long long* gmin = d_csstats + 4096;
             const size_t lds = (size_t)(iters > 0 ? 2 * iters : 2) * sizeof(unsigned long long);

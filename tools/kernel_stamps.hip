@@ -58,6 +58,11 @@ template <class Launch>
 static void report(const char* name, int tiles, int waves, Launch&& launch, const char* const* nm = kStripSections) {
     for (int k = 0; k < 30; ++k) launch();
     CK(hipDeviceSynchronize());
+    {
+        void* sym = nullptr;
+        CK(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_stamps)));
+        CK(hipMemset(sym, 0, sizeof(unsigned long long) * (size_t)kStampTiles * kStampWaves * kStampSlots));
+    }
     launch();
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> st((size_t)kStampTiles * kStampWaves * kStampSlots);
@@ -67,12 +72,14 @@ static void report(const char* name, int tiles, int waves, Launch&& launch, cons
     for (int t = 0; t < std::min(tiles, kStampTiles); ++t)
         for (int w = 0; w < waves; ++w) {
             const unsigned long long* s = &st[((size_t)t * kStampWaves + w) * kStampSlots];
+            if (s[0] == 0 || s[5] == 0) continue;  // (a wave without a node)
             first = std::min(first, s[0]);
             last = std::max(last, s[5]);
         }
     for (int t = 0; t < std::min(tiles, kStampTiles); ++t)
         for (int w = 0; w < waves; ++w) {
             const unsigned long long* s = &st[((size_t)t * kStampWaves + w) * kStampSlots];
+            if (s[0] == 0 || s[5] == 0) continue;
             sec[0].push_back(10.0 * (double)(s[0] - first));
             for (int k = 1; k <= 5; ++k) sec[k].push_back(10.0 * (double)(s[k] - s[k - 1]));
         }
@@ -225,7 +232,7 @@ int main(int argc, char** argv) {
         static const char* nm[6] = {"start after the first wave", "arguments + loads", "forcing of t1 (tables, 5 stores)",
                                     "field F(S0, t0)", "predictors, b_T, corrector parts", "stores drained"};
         report("predictor launch with the prologue", (int)(grid.x * grid.y), 4, [&]() {
-            hipLaunchKernelGGL((k_nodes_pro<decltype(f)>), grid, block, 0, 0, f, 0, nrows, ncols, ra, stats, stats + 32);
+            hipLaunchKernelGGL((k_nodes_pro<decltype(f)>), grid, block, 0, 0, f, 0, nrows, ncols, ra, stats, stats + 32, false);
         }, nm);
         // ---- record pass of the cs corrector
         CorrectIn<CASE_STREAM, REACT_REG> ci{g, m, field(0.3, 0.1), field(0.08, 0.02), cs1, Tn, cln, cdo, dt};
