@@ -106,6 +106,8 @@ int tedd_set_mms_program(tedd_ctx* ctx, int32_t which, const uint32_t* code, int
  * slabs of at most 4 M nodes): those arrays are made by the predictor launch instead of a launch of their own;
  * "fuse_rhs" (default -1: slabs of at most 4 M nodes): a cl or cd solve that is a single launch evaluates its
  * right-hand side itself instead of reading it from an array a launch of its own wrote (bit-identical results);
+ * "fuse_corrector" (default 1): such a cd launch of the last Newton step also carries the cp corrector and the
+ * record pass of the RegHCsTriple cs corrector on whole-mesh contexts (one launch fewer, bit-identical results);
  * "warm_start" (default 1): a Newton solve whose sweep count the library chooses starts its Jacobi iteration
  * from the increment of the step before instead of zero (same tolerance, fewer sweeps); "march" (default -1:
  * slabs of at least 2^25 nodes; 0 never, 1 always): the predictor and the right-hand sides of the cl and cd

@@ -1167,6 +1167,9 @@ public:
     // tile halos costs more than the passes: 16384^2, rhs + solve launches 6.75 / 8.66 ms against 6.79 / 9.47 fused)
     int opt_fuse_rhs = -1;
     int opt_exact_faces = 0;  // (test hook, see StripArgs::xface)
+    // the last launch of a cd chain that evaluates its right-hand side also carries the record pass of the cs
+    // corrector (RegHCsTriple, whole-mesh slabs): one launch fewer per step, same results
+    int opt_fuse_corrector = 1;
     bool fuse_rhs_now() const {
         return opt_fuse_rhs < 0 ? (size_t)nrows * ncols <= ((size_t)1 << 22) : opt_fuse_rhs != 0;
     }
@@ -1197,9 +1200,17 @@ public:
 
     // Register-resident solve chain (tedd_strip.hpp): b = delta^1 = rhs/diag from the node kernel,
     // then ceil((nsweeps-1)/hmax) launches that iterate on (b, delta).
+    // Corrector the last launch of a cd chain may carry (tedd_strip.hpp, CORR): filled in by the step, `done` set
+    // by the solve if its launch took it.
+    struct CorrFuse {
+        const double *ncp = nullptr, *ycs = nullptr, *cs0 = nullptr;
+        double *cp_out = nullptr, *cs_out = nullptr;
+        int iters = 0;
+        bool done = false;
+    };
     template <int VAR, int CASE, int REACT>
     void newton_solve_strip(const StepParams& p, const ForcingSrc& f1, const NewtonIn& a, double* unew, int nsweeps,
-                            int slot_id, const double* u_prev) {
+                            int slot_id, const double* u_prev, CorrFuse* cf = nullptr) {
         if constexpr (Backend::kHasStripSolve) {
             const int fam = (VAR == VAR_T) ? FAM_SOLVE_T : (VAR == VAR_CL) ? FAM_SOLVE_CL : FAM_SOLVE_CD;
             const int fam_rhs = (VAR == VAR_T) ? FAM_RHS_T : (VAR == VAR_CL) ? FAM_RHS_CL : FAM_RHS_CD;
@@ -1278,6 +1289,22 @@ public:
                 A.d_out = dout;
                 A.u_out = lastl ? unew : nullptr;
                 if (lastl) {
+                    if constexpr (VAR == VAR_CD && REACT == REACT_REG) {
+                        // the record pass of the cs corrector rides on this launch where it can (whole-mesh
+                        // slabs: the launch writes every node exactly once)
+                        if (cf && fused && !warm_first && gl == 0 && gr == 0 && r.lo == 0 && r.hi == nrows &&
+                            be.can_fuse_corrector(cf->iters)) {
+                            A.ncp = cf->ncp;
+                            A.ycs = cf->ycs;
+                            A.cs0 = cf->cs0;
+                            A.cp_out = cf->cp_out;
+                            A.cs_out = cf->cs_out;
+                            A.cs_iters = cf->iters;
+                            A.gmax = be.cs_record_max();
+                            A.gmin = be.cs_record_min();
+                            cf->done = true;
+                        }
+                    }
                     be.template solve_strip<VAR, REACT, true>(fam, A, ncols, opt_strip_shape);
                     mark(unew, r);
                 } else {
@@ -1291,10 +1318,10 @@ public:
 
     template <int VAR, int CASE, int REACT>
     void newton_solve(const StepParams& p, const ForcingSrc& f1, const NewtonIn& a, double* unew, int nsweeps, int slot_id,
-                      const double* u_prev = nullptr) {
+                      const double* u_prev = nullptr, CorrFuse* cf = nullptr) {
         if constexpr (Backend::kHasStripSolve) {
             if (strip_now()) {
-                newton_solve_strip<VAR, CASE, REACT>(p, f1, a, unew, nsweeps, slot_id, u_prev);
+                newton_solve_strip<VAR, CASE, REACT>(p, f1, a, unew, nsweeps, slot_id, u_prev, cf);
                 return;
             }
         }
@@ -1455,6 +1482,9 @@ public:
         double* cp_last_used = nullptr;
         double* cs_last_used = nullptr;
         for (int pc = 0; pc < p.num_pc; ++pc) {
+            double* cpN = grab();
+            double* csN = grab();
+            CorrFuse cf;
             for (int nw = 0; nw < p.num_newton; ++nw) {
                 double* Tn = grab();
                 double* cln = grab();
@@ -1475,18 +1505,30 @@ public:
                 const bool first = (pc == 0 && nw == 0);
                 newton_solve<VAR_T, CASE, REACT>(p, f1, a, Tn, p.sweeps[0], 0, first && p.warm[0] ? prev[0] : nullptr);
                 newton_solve<VAR_CL, CASE, REACT>(p, f1, a, cln, p.sweeps[1], 1, first && p.warm[1] ? prev[1] : nullptr);
-                newton_solve<VAR_CD, CASE, REACT>(p, f1, a, cdn, p.sweeps[2], 2, first && p.warm[2] ? prev[2] : nullptr);
+                CorrFuse* cfp = nullptr;
+                if (Backend::kHasStripSolve && REACT == REACT_REG && nw == p.num_newton - 1 && opt_fuse_corrector) {
+                    cf.ncp = ncp;
+                    cf.ycs = ycs;
+                    cf.cs0 = cur[VAR_CS];
+                    cf.cp_out = cpN;
+                    cf.cs_out = csN;
+                    cf.iters = p.cs_iters;
+                    cfp = &cf;
+                }
+                newton_solve<VAR_CD, CASE, REACT>(p, f1, a, cdn, p.sweeps[2], 2, first && p.warm[2] ? prev[2] : nullptr, cfp);
                 To = Tn;
                 clo = cln;
                 cdo = cdn;
                 cp_last_used = cpU;
                 cs_last_used = csU;
             }
-            double* cpN = grab();
-            double* csN = grab();
             CorrectIn<CASE, REACT> ci{g, model, ncp, ycs, cur[VAR_CS], To, clo, cdo, dt};
             Range r = need({{ncp, false}, {ycs, false}, {cur[VAR_CS], false}, {To, false}, {clo, false}, {cdo, false}});
-            be.template correct<CASE, REACT>(ci, r.lo, r.hi, ncols, cpN, csN, p.cs_iters, p.cs_rtol, d_ints);
+            if constexpr (Backend::kHasStripSolve) {
+                be.template correct<CASE, REACT>(ci, r.lo, r.hi, ncols, cpN, csN, p.cs_iters, p.cs_rtol, d_ints, cf.done);
+            } else {
+                be.template correct<CASE, REACT>(ci, r.lo, r.hi, ncols, cpN, csN, p.cs_iters, p.cs_rtol, d_ints);
+            }
             mark(cpN, r);
             mark(csN, r);
             cpU = cpN;
@@ -1702,6 +1744,8 @@ public:
             opt_strip_shape = (int)value;
         else if (name == "fuse_rhs")
             opt_fuse_rhs = value < 0.0 ? -1 : (value != 0.0);
+        else if (name == "fuse_corrector")
+            opt_fuse_corrector = value != 0.0;
         else if (name == "cache_forcing")
             opt_cache_forcing = value != 0.0;
         else if (name == "fuse_forcing")

@@ -1133,8 +1133,20 @@ struct HipBackend {
             else
                 launch(shape_c, std::false_type{}, fused_c, xface_c);
         };
+        const bool corr = (A.cp_out != nullptr);
+        if (corr && !(fused && !warm && VAR == VAR_CD && REACT == REACT_REG && LAST && shape != SHAPE_LARGE))
+            throw std::runtime_error("this strip launch cannot carry the corrector");
+        if (corr && (A.cs_iters < 0 || A.cs_iters > kStripCsRegs || !A.ncp || !A.ycs || !A.cs0 || !A.cs_out || !A.gmax || !A.gmin))
+            throw std::runtime_error("fused corrector: bad arguments");
         auto by_fused = [&](auto shape_c) {
             constexpr int SH = decltype(shape_c)::value;
+            if constexpr (LAST && VAR == VAR_CD && REACT == REACT_REG && SH != SHAPE_LARGE) {
+                if (corr) {
+                    hipLaunchKernelGGL((k_solve_strip<VAR, REACT, LAST, SH, false, true, false, true>), dim3((unsigned)nt),
+                                       dim3(kSTile, StripShape<VAR, SH>::W), 0, stream, A);
+                    return;
+                }
+            }
             if constexpr (LAST && VAR != VAR_T && SH != SHAPE_LARGE) {
                 if (fused) {
                     by_warm(shape_c, std::true_type{}, std::false_type{});
@@ -1158,9 +1170,16 @@ struct HipBackend {
             by_fused(std::integral_constant<int, SHAPE_LARGE>{});
         TEDD_HIP(hipGetLastError());
     }
+    // Can the last launch of a cd chain carry the record pass of the cs corrector (k_solve_strip, CORR)?
+    bool can_fuse_corrector(int iters) const {
+        return !rec_on && !reduce_hook && iters >= 0 && iters <= kStripCsRegs && cs_record_clean >= iters;
+    }
+    unsigned long long* cs_record_max() { return d_csstats; }
+    unsigned long long* cs_record_min() { return d_csstats + 4096; }
+    // skip_record: the record pass was carried by the cd solve launch; only the deciding pass is left
     template <int CASE, int REACT>
     void correct(const CorrectIn<CASE, REACT>& a, int r0, int r1, int ncols, double* cp_out, double* cs_out, int iters,
-                 double rtol, int* d_keep) {
+                 double rtol, int* d_keep, bool skip_record = false) {
         check_range(r0, r1, ncols);
         if (r1 == r0) return;
         if constexpr (REACT != REACT_REG) {
@@ -1211,11 +1230,13 @@ struct HipBackend {
                 per_cu = n;
             }
             nb = std::min(nb, per_cu * num_cus);
-            if (iters > 0 && cs_record_clean < iters)
-                hipLaunchKernelGGL(k_cs_init, dim3((iters + 255) / 256), dim3(256), 0, stream, gmax, gmin, iters);
+            if (!skip_record) {
+                if (iters > 0 && cs_record_clean < iters)
+                    hipLaunchKernelGGL(k_cs_init, dim3((iters + 255) / 256), dim3(256), 0, stream, gmax, gmin, iters);
+                hipLaunchKernelGGL(k_cs_newton<CASE>, dim3(nb), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx, nt,
+                                   cp_out, cs_out, iters, true, rtol, d_keep, gmax, gmin);
+            }
             cs_record_clean = 0;
-            hipLaunchKernelGGL(k_cs_newton<CASE>, dim3(nb), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx, nt,
-                               cp_out, cs_out, iters, true, rtol, d_keep, gmax, gmin);
             // the record holds bit patterns of non-negative doubles (+inf where nothing was seen): their
             // order as doubles is their order as integers, so the hook may reduce them as doubles
             if (reduce_hook && iters > 0) {

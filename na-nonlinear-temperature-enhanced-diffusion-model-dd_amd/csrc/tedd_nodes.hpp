@@ -575,6 +575,13 @@ struct StripArgs {
     // test hook (single-launch cl / cd chains that read b from an array): build the matrix rows from face
     // values evaluated as a fused launch evaluates them, so that the two can be compared bit for bit
     int xface = 0;
+    // corrector carried by the launch (cd chain of RegHCsTriple with its right-hand side fused in, last Newton
+    // step): every node the launch writes also gets the cp trapezoid and the record pass of the cs Newton
+    // iteration (the six values it reads are the three below and the new T, cl, cd the thread holds)
+    const double *ncp = nullptr, *ycs = nullptr, *cs0 = nullptr;
+    double *cp_out = nullptr, *cs_out = nullptr;
+    int cs_iters = 0;
+    unsigned long long *gmax = nullptr, *gmin = nullptr;
 };
 
 // Convergence record of the Newton solves of one step (device memory, `red`):

@@ -168,10 +168,15 @@ __device__ __forceinline__ double wave_max_nan_inf(double v) { return wave_max_n
 // cl rows use Dl at a face = Dl_max e_a e_b with one exponential e = exp(-phi_l c / 2) per node, and the cd
 // rows law_Dd: cheaper, equal to rounding, and what the launches that read b from an array use; the exact
 // variant of those launches exists so that a fused launch can be checked against them bit for bit.
-template <int VAR, int REACT, bool LAST, int SHAPE, bool WARM = false, bool FUSED = false, bool XFACE = false>
+// CORR (cd chain of RegHCsTriple with FUSED, its last launch): the launch carries the corrector of cp and the
+// record pass of the cs corrector for the nodes it writes (the arithmetic of k_cs_newton's record pass on the
+// same values: the new T, cl and cd are in the thread's registers), one launch fewer per step on small slabs.
+constexpr int kStripCsRegs = 8;  // cs Newton iterations a fused corrector keeps the record of (as k_cs_newton's registers)
+template <int VAR, int REACT, bool LAST, int SHAPE, bool WARM = false, bool FUSED = false, bool XFACE = false, bool CORR = false>
 __global__ void __launch_bounds__((64 * StripShape<VAR, SHAPE>::W))
 __attribute__((amdgpu_waves_per_eu((FUSED ? StripShape<VAR, SHAPE>::OCC_FUSED : StripShape<VAR, SHAPE>::OCC))))
 k_solve_strip(const StripArgs A) {
+    static_assert(!CORR || (FUSED && VAR == VAR_CD && REACT == REACT_REG && !WARM), "fused corrector: cd chain of RegHCsTriple");
     constexpr int R = StripShape<VAR, SHAPE>::R, W = StripShape<VAR, SHAPE>::W, TR = StripShape<VAR, SHAPE>::TR;
     constexpr bool LEAN = (VAR == VAR_T);
     constexpr int kBatch = (R > 4) ? 4 : R;  // rows whose late loads (warm iterate, lagged unknown) are in flight together
@@ -233,11 +238,23 @@ k_solve_strip(const StripArgs A) {
     // one fewer).
     unsigned long long stat_seen = 0ull;
     if (LAST) stat_seen = __atomic_load_n(A.stats + (lane & 1), __ATOMIC_RELAXED);
+    // fused corrector: its three inputs at the thread's nodes, and the record words lane k may move at the end
+    double ncpv[CORR ? R : 1], ycsv[CORR ? R : 1], cs0v[CORR ? R : 1];
+    unsigned long long cs_seen_mx = 0ull, cs_seen_mn = 0xFFFFFFFFFFFFFFFFull;
+    if (CORR && wave == 0 && lane < A.cs_iters) {
+        cs_seen_mx = __atomic_load_n(A.gmax + lane, __ATOMIC_RELAXED);
+        cs_seen_mn = __atomic_load_n(A.gmin + lane, __ATOMIC_RELAXED);
+    }
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const size_t c = (size_t)min(max(row0 + k, 0), rmax) * g.ld + jc;
         if (!FUSED) b[k] = A.b_in[c];
         if (UOLD_EARLY) uold_e[k] = A.a.To[c];
+        if (CORR) {
+            ncpv[k] = get_once(A.ncp + c);
+            ycsv[k] = get_once(A.ycs + c);
+            cs0v[k] = A.cs0[c];
+        }
         if (LEAN && !WARM) d[k] = A.d_in[c];  // (the same line as b[k] in the first launch of a cold chain)
         if (VAR == VAR_CD) {
             clv[k] = A.a.clo[c];
@@ -567,6 +584,14 @@ k_solve_strip(const StripArgs A) {
     int row0w = row0, jw = j;
     asm volatile("" : "+s"(row0w));
     asm volatile("" : "+v"(jw));
+    double cs_rmx[CORR ? kStripCsRegs : 1], cs_rmn[CORR ? kStripCsRegs : 1];
+    if (CORR) {
+#pragma unroll
+        for (int q = 0; q < kStripCsRegs; ++q) {
+            cs_rmx[CORR ? q : 0] = 0.0;
+            cs_rmn[CORR ? q : 0] = INFINITY;
+        }
+    }
     if (LAST) {
         // the lagged unknown of a batch of rows first (clamped coordinates, unconditional), then the stores
 #pragma unroll
@@ -588,12 +613,37 @@ k_solve_strip(const StripArgs A) {
                 const int li = row0w + k;
                 if (r >= H && r < TR - H && li >= A.r0 && li < A.r1 && lane_in) {
                     const size_t c = at(g, li, jw);
-                    if (is_interior(g, li, jw)) {
-                        A.u_out[c] = uold[k - k0] + d[k];
+                    const bool in = is_interior(g, li, jw);
+                    double unew;
+                    if (in) {
+                        unew = uold[k - k0] + d[k];
                         const double mag = fabs(d[k]);
                         mag_max = (mag > mag_max || mag != mag) ? mag : mag_max;
                     } else {
-                        A.u_out[c] = (VAR == VAR_T) ? 0.0 : uold[k - k0];
+                        unew = (VAR == VAR_T) ? 0.0 : uold[k - k0];
+                    }
+                    A.u_out[c] = unew;
+                    if (CORR) {
+                        const CsNodeIn v{ncpv[CORR ? k : 0], ycsv[CORR ? k : 0], cs0v[CORR ? k : 0], Tnv[FUSED ? k + 1 : 0],
+                                         clnv[(FUSED && VAR == VAR_CD) ? k : 0], unew};
+                        put_once(A.cp_out + c, corrector_cp_vals(m, A.dt, v, in));
+                        double x, y, av;
+                        cs_newton_inputs_vals(m, A.dt, v, y, av, x);
+                        double ex = cs_newton_exp(x, m.eta);
+#pragma unroll
+                        for (int q = 0; q < kStripCsRegs; ++q) {
+                            if (q < A.cs_iters) {
+                                const double dx = cs_newton_step(x, y, av, m.eta, ex);
+                                x = x + dx;
+                                if (q + 1 < A.cs_iters) ex = cs_newton_exp_next(ex, x, dx, m.eta);
+                                double adx = fabs(dx), ax = fabs(x);
+                                if (adx != adx) adx = INFINITY;
+                                if (ax != ax) ax = 0.0;
+                                cs_rmx[CORR ? q : 0] = adx > cs_rmx[CORR ? q : 0] ? adx : cs_rmx[CORR ? q : 0];
+                                cs_rmn[CORR ? q : 0] = ax < cs_rmn[CORR ? q : 0] ? ax : cs_rmn[CORR ? q : 0];
+                            }
+                        }
+                        put_once(A.cs_out + c, in ? x : 0.0 * x);
                     }
                 }
             }
@@ -608,8 +658,37 @@ k_solve_strip(const StripArgs A) {
         }
     }
     TEDD_STAMP(4);
+    // fused corrector: the wave's per-iteration record (lane q keeps iteration q), one set of plain LDS words per wave
+    __shared__ unsigned long long cs_wrec[CORR ? W : 1][2 * kStripCsRegs];
+    if (CORR) {
+        double mine_mx = 0.0, mine_mn = INFINITY;
+#pragma unroll
+        for (int q = 0; q < kStripCsRegs; ++q) {
+            if (q < A.cs_iters) {
+                const double wmx = wave_max_nn(cs_rmx[CORR ? q : 0]), wmn = wave_min_nn(cs_rmn[CORR ? q : 0]);
+                if (lane == q) {
+                    mine_mx = wmx;
+                    mine_mn = wmn;
+                }
+            }
+        }
+        if (lane < A.cs_iters) {
+            cs_wrec[CORR ? wave : 0][lane] = (unsigned long long)__double_as_longlong(mine_mx);
+            cs_wrec[CORR ? wave : 0][kStripCsRegs + lane] = (unsigned long long)__double_as_longlong(mine_mn);
+        }
+    }
     if (LAST) {
         __syncthreads();  // the seam rows are dead: reuse their first doubles
+        if (CORR && wave == 0 && lane < A.cs_iters) {
+            unsigned long long mx = cs_wrec[0][lane], mn = cs_wrec[0][kStripCsRegs + lane];
+#pragma unroll
+            for (int w2 = 1; w2 < (CORR ? W : 1); ++w2) {
+                mx = cs_wrec[CORR ? w2 : 0][lane] > mx ? cs_wrec[CORR ? w2 : 0][lane] : mx;
+                mn = cs_wrec[CORR ? w2 : 0][kStripCsRegs + lane] < mn ? cs_wrec[CORR ? w2 : 0][kStripCsRegs + lane] : mn;
+            }
+            if (mx > cs_seen_mx) atomicMax(A.gmax + lane, mx);
+            if (mn < cs_seen_mn) atomicMin(A.gmin + lane, mn);
+        }
         double* red = &seam[0][0][0][0];
         up_max = wave_max_nan_inf(up_max);
         mag_max = wave_max_nan_inf(mag_max);

@@ -44,7 +44,7 @@ SOLVERS = {"strip": {"strip_solve": 1}, "strip_large": {"strip_shape": 0}, "stri
            "strip_two_rows_h3": {"strip_shape": 3, "strip_hmax": 3}, "strip_h1": {"strip_solve": 1, "strip_hmax": 1},
            "strip_h2": {"strip_solve": 1, "strip_hmax": 2}, "strip_h3": {"strip_solve": 1, "strip_hmax": 3},
            "sweeps": {"strip_solve": 0}, "forcing_in_kernels": {"cache_forcing": 0},
-           "forcing_launch": {"fuse_forcing": 0}, "rhs_launch": {"fuse_rhs": 0}, "march": {"march": 1, "fuse_forcing": 0},
+           "forcing_launch": {"fuse_forcing": 0}, "rhs_launch": {"fuse_rhs": 0}, "corrector_launch": {"fuse_corrector": 0}, "march": {"march": 1, "fuse_forcing": 0},
            "sweeps_forcing_in_kernels": {"strip_solve": 0, "cache_forcing": 0}}
 
 

@@ -154,3 +154,41 @@ def test_tile_order_of_the_solve_launches_changes_nothing(panel):
     got, _ = _run_solve(300, 280, _ffi.REACT_REGHCSTRIPLE, {"strip_panel": panel}, steps=2, sweeps=(6, 4, 3))
     for a, b in zip(ref, got):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("N,M", [(32, 32), (131, 200), (256, 256), (70, 300)])
+def test_corrector_carried_by_the_cd_solve_is_bit_identical(N, M):
+    """On small slabs the last launch of the cd chain also carries the cp corrector and the record pass of the
+    cs corrector (RegHCsTriple): the same functions on the same values as the corrector's own launch, so states,
+    records and the iteration count agree bit for bit -- also with 2 Newton x 2 predictor-corrector iterations
+    (only the last Newton step of the first carries it) and with the global early exit of the cs iteration."""
+    from test_gpu_persistent import NB_A, _early_exit_run
+
+    def run(opts, **kw):
+        x = np.linspace(0, 1, N + 1) ** 1.04
+        y = np.linspace(0, 1, M + 1) ** 0.97
+        ctx = _ffi.Context(x, y, NB_A, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0, mms_case=_ffi.MMS_EXPSIN)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.set_state_exact(0.0)
+        dt = (1.0 / max(N, M)) ** 1.5
+        series = ctx.advance(0.0, dt, 5, **kw)
+        st = ctx.get_stats()
+        out = ctx.get_state()
+        ctx.close()
+        return series, out, st
+
+    for kw in ({}, {"num_pc_steps": 2, "num_newton_steps": 2}, {"cs_newton_iterations": 8}, {"cs_newton_iterations": 1}):
+        ref = run({"fuse_corrector": 0}, **kw)
+        got = run({}, **kw)
+        np.testing.assert_array_equal(ref[0], got[0])
+        for a, b in zip(ref[1], got[1]):
+            np.testing.assert_array_equal(a, b, err_msg=str(kw))
+        assert ref[2]["cs_iterations"] == got[2]["cs_iterations"] and ref[2]["last_update"] == got[2]["last_update"]
+    if (N, M) == (32, 32):
+        kept_ref, ref = _early_exit_run({"fuse_corrector": 0})
+        kept, got = _early_exit_run({})
+        assert kept == kept_ref and all(1 <= k < 8 for k in kept)
+        for sa, sb in zip(ref, got):
+            for a, b in zip(sa, sb):
+                np.testing.assert_array_equal(a, b)
