@@ -1293,7 +1293,8 @@ public:
                         // the record pass of the cs corrector rides on this launch where it can (whole-mesh
                         // slabs: the launch writes every node exactly once)
                         if (cf && fused && !warm_first && gl == 0 && gr == 0 && r.lo == 0 && r.hi == nrows &&
-                            be.can_fuse_corrector(cf->iters)) {
+                            be.can_fuse_corrector(cf->iters) &&
+                            be.strip_shape_carries_corrector(be.strip_shape_for(VAR, A.H, r.lo, r.hi, ncols, opt_strip_shape))) {
                             A.ncp = cf->ncp;
                             A.ycs = cf->ycs;
                             A.cs0 = cf->cs0;

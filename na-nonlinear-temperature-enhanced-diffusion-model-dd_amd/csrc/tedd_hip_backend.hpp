@@ -216,7 +216,7 @@ __device__ __forceinline__ bool cs_stop_after(const unsigned long long* gmax, co
                                               double rtol) {
     return __longlong_as_double((long long)gmax[k]) < rtol * __longlong_as_double((long long)gmin[k]);
 }
-template <int CASE>
+template <int CASE, bool FLAT = false>
 __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_REG> a, int r0, int r1, int ncols,
                                                   int tiles_x, int ntiles, double* cp_out, double* cs_out, int iters,
                                                   bool record, double rtol, int* out_keep, unsigned long long* gmax,
@@ -262,9 +262,9 @@ __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_R
     }
     // a workgroup walks over its tiles; the six values a node reads are requested one tile ahead, so that
     // the iteration of the present tile runs while they travel
-    // (tiles_x == 0: "tiles" are runs of 256 consecutive nodes of the rows, see k_nodes)
+    // (FLAT: "tiles" are runs of 256 consecutive nodes of the rows, see k_nodes)
     auto place = [&](int t, int& j, int& li) {
-        if (tiles_x == 0) {
+        if (FLAT) {
             const int q = t * (kTileX * kTileY) + tid;
             const int row = q / ncols;
             li = r0 + row;
@@ -1134,13 +1134,13 @@ struct HipBackend {
                 launch(shape_c, std::false_type{}, fused_c, xface_c);
         };
         const bool corr = (A.cp_out != nullptr);
-        if (corr && !(fused && !warm && VAR == VAR_CD && REACT == REACT_REG && LAST && shape != SHAPE_LARGE))
+        if (corr && !(fused && !warm && VAR == VAR_CD && REACT == REACT_REG && LAST && strip_shape_carries_corrector(shape)))
             throw std::runtime_error("this strip launch cannot carry the corrector");
         if (corr && (A.cs_iters < 0 || A.cs_iters > kStripCsRegs || !A.ncp || !A.ycs || !A.cs0 || !A.cs_out || !A.gmax || !A.gmin))
             throw std::runtime_error("fused corrector: bad arguments");
         auto by_fused = [&](auto shape_c) {
             constexpr int SH = decltype(shape_c)::value;
-            if constexpr (LAST && VAR == VAR_CD && REACT == REACT_REG && SH != SHAPE_LARGE) {
+            if constexpr (LAST && VAR == VAR_CD && REACT == REACT_REG && (SH == SHAPE_SMALL || SH == SHAPE_TINY)) {
                 if (corr) {
                     hipLaunchKernelGGL((k_solve_strip<VAR, REACT, LAST, SH, false, true, false, true>), dim3((unsigned)nt),
                                        dim3(kSTile, StripShape<VAR, SH>::W), 0, stream, A);
@@ -1170,6 +1170,8 @@ struct HipBackend {
             by_fused(std::integral_constant<int, SHAPE_LARGE>{});
         TEDD_HIP(hipGetLastError());
     }
+    // the tile shapes of small meshes (the corrector needs ~50 registers more than the 48-row tiles' budget has)
+    static bool strip_shape_carries_corrector(int shape) { return shape == SHAPE_SMALL || shape == SHAPE_TINY; }
     // Can the last launch of a cd chain carry the record pass of the cs corrector (k_solve_strip, CORR)?
     bool can_fuse_corrector(int iters) const {
         return !rec_on && !reduce_hook && iters >= 0 && iters <= kStripCsRegs && cs_record_clean >= iters;
@@ -1211,7 +1213,8 @@ struct HipBackend {
             Scope sc(this, FAM_CS_NEWTON);
             int tx, nt, nb;
             tiling(r0, r1, ncols, tx, nt, nb);
-            if (flat_nodes(r0, r1, ncols)) {  // (runs of 256 nodes instead of 64 x 4 tiles: see k_nodes)
+            const bool flat = flat_nodes(r0, r1, ncols);
+            if (flat) {  // (runs of 256 nodes instead of 64 x 4 tiles: see k_nodes)
                 tx = 0;
                 nt = (int)(((long long)(r1 - r0) * ncols + kTileX * kTileY - 1) / (kTileX * kTileY));
                 nb = nt < kMaxReduceBlocks ? nt : kMaxReduceBlocks;
@@ -1225,7 +1228,7 @@ struct HipBackend {
             static int per_cu = 0;
             if (per_cu == 0) {
                 int n = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cs_newton<CASE>, kTileX * kTileY, lds) != hipSuccess || n < 1)
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cs_newton<CASE, false>, kTileX * kTileY, lds) != hipSuccess || n < 1)
                     n = 4;
                 per_cu = n;
             }
@@ -1233,8 +1236,12 @@ struct HipBackend {
             if (!skip_record) {
                 if (iters > 0 && cs_record_clean < iters)
                     hipLaunchKernelGGL(k_cs_init, dim3((iters + 255) / 256), dim3(256), 0, stream, gmax, gmin, iters);
-                hipLaunchKernelGGL(k_cs_newton<CASE>, dim3(nb), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx, nt,
-                                   cp_out, cs_out, iters, true, rtol, d_keep, gmax, gmin);
+                if (flat)
+                    hipLaunchKernelGGL((k_cs_newton<CASE, true>), dim3(nb), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols,
+                                       tx, nt, cp_out, cs_out, iters, true, rtol, d_keep, gmax, gmin);
+                else
+                    hipLaunchKernelGGL((k_cs_newton<CASE, false>), dim3(nb), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols,
+                                       tx, nt, cp_out, cs_out, iters, true, rtol, d_keep, gmax, gmin);
             }
             cs_record_clean = 0;
             // the record holds bit patterns of non-negative doubles (+inf where nothing was seen): their
@@ -1248,8 +1255,11 @@ struct HipBackend {
             // meshes it is launched with few workgroups (what it costs is their number: 3.5 us for the 325 of a
             // 256^2 mesh), each of which walks over 16 tiles in the rare case that it has to iterate again.
             const int nb2 = (nt <= 4096) ? std::min(nb, std::max(32, nt / 16)) : nb;
-            if (iters > 1)
-                hipLaunchKernelGGL(k_cs_newton<CASE>, dim3(nb2), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx,
+            if (iters > 1 && flat)
+                hipLaunchKernelGGL((k_cs_newton<CASE, true>), dim3(nb2), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx,
+                                   nt, cp_out, cs_out, iters, false, rtol, d_keep, gmax, gmin);
+            else if (iters > 1)
+                hipLaunchKernelGGL((k_cs_newton<CASE, false>), dim3(nb2), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx,
                                    nt, cp_out, cs_out, iters, false, rtol, d_keep, gmax, gmin);
             else
                 hipLaunchKernelGGL(k_cs_decide, dim3(1), dim3(1), 0, stream, gmax, gmin, iters, rtol, d_keep);

@@ -236,8 +236,10 @@ k_solve_strip(const StripArgs A) {
     // The record words this launch may raise at its very end, read now: most tiles find at the end that they do
     // not raise them, without a round trip there (a value read too early is too small: one atomic more, never
     // one fewer).
+    // (the tiles of small meshes only: the others have no registers to carry it across their sweeps)
+    constexpr bool STAT_EARLY = LAST && (SHAPE == SHAPE_SMALL || SHAPE == SHAPE_TINY);
     unsigned long long stat_seen = 0ull;
-    if (LAST) stat_seen = __atomic_load_n(A.stats + (lane & 1), __ATOMIC_RELAXED);
+    if (STAT_EARLY) stat_seen = __atomic_load_n(A.stats + (lane & 1), __ATOMIC_RELAXED);
     // fused corrector: its three inputs at the thread's nodes, and the record words lane k may move at the end
     double ncpv[CORR ? R : 1], ycsv[CORR ? R : 1], cs0v[CORR ? R : 1];
     unsigned long long cs_seen_mx = 0ull, cs_seen_mn = 0xFFFFFFFFFFFFFFFFull;
@@ -706,6 +708,7 @@ k_solve_strip(const StripArgs A) {
             if (v != v) v = INFINITY;
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
             // most tiles do not raise the maximum: skip their atomics
+            if (!STAT_EARLY) stat_seen = __atomic_load_n(A.stats + lane, __ATOMIC_RELAXED);
             if (bits > stat_seen) atomicMax(A.stats + lane, bits);
         }
     }

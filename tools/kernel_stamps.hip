@@ -248,7 +248,7 @@ int main(int argc, char** argv) {
         static const char* nc[6] = {"start after the first wave", "arguments + loads", "cp trapezoid + 5 Newton iterations",
                                     "wave reductions + LDS record", "workgroup barrier", "global record + drain"};
         report("cs corrector, record pass", nt, 4, [&]() {
-            hipLaunchKernelGGL((k_cs_newton<CASE_STREAM>), dim3(nt), dim3(kTileX, kTileY), 10 * sizeof(unsigned long long), 0, ci,
+            hipLaunchKernelGGL((k_cs_newton<CASE_STREAM, false>), dim3(nt), dim3(kTileX, kTileY), 10 * sizeof(unsigned long long), 0, ci,
                                0, nrows, ncols, tx, nt, cpo, cso, 5, true, 1e-6, keep, cst, cst + 4096);
         }, nc);
     }
