@@ -115,6 +115,8 @@ public:
     int cold_spell[3] = {kColdSpell, kColdSpell, kColdSpell};
     double* d_series = nullptr;   // error-norm series of tedd_advance
     size_t series_cap = 0;
+    double* d_partials_all = nullptr;  // partial sums of the norms of all steps of a tedd_advance call
+    size_t partials_cap = 0;
     int* d_ints = nullptr;        // [0] cs iterations kept, [1] HCsTriple corrector: denominator not positive
 
     // record of the last PC step (for residuals and stats)
@@ -218,6 +220,7 @@ public:
         be.free(d_pyq);
         be.free(d_red);
         be.free(d_series);
+        be.free(d_partials_all);
         be.free(d_ints);
         be.sync_quiet();  // a prologue launch may still be writing the ring
         be.free_host_visible(h_ring);
@@ -791,6 +794,7 @@ public:
         double t;
         double* dev_out;
         bool noalloc = false;
+        double* partials_out = nullptr;  // leave the partial sums there, no final pass (advance finishes them all at its end)
         template <int CASE, int REACT>
         void run() {
             Ctx& C = *c;
@@ -810,10 +814,13 @@ public:
             Range r = C.need({{C.cur[1], true}, {C.cur[2], true}, {C.cur[3], true}});
             if ((C.gl > 0 || C.gr > 0) && (r.lo > o.lo || r.hi < o.hi))
                 throw InvalidError("ghost rows are stale: exchange them before taking norms");
-            if (noalloc)
+            if (noalloc) {
                 C.be.nodes_sum_noalloc(f, o.lo, o.hi, C.ncols, dev_out);
-            else
+            } else if (partials_out) {
+                if constexpr (Backend::kHasPersist) C.be.nodes_sum(FAM_NORMS, f, o.lo, o.hi, C.ncols, dev_out, partials_out);
+            } else {
                 C.be.nodes_sum(FAM_NORMS, f, o.lo, o.hi, C.ncols, dev_out);
+            }
         }
     };
     // Largest slab tedd_error_norms_noalloc accepts (nodes, ghost rows included): 2^26, a quarter of the
@@ -1827,15 +1834,48 @@ public:
             d_series = (double*)be.alloc(need_elems * sizeof(double));
             series_cap = need_elems;
         }
+        // The sum launches of the norms leave partial sums; where they fit a modest array, their final passes
+        // (one small launch each: 2.7 us of a 50 us step at 256^2) are all taken at the end of the run, as one launch.
+        double* partials_all = nullptr;
+        int sum_nb = 0;
+        if constexpr (Backend::kHasPersist) {
+            const Range o = owned();
+            sum_nb = be.sum_blocks(o.lo, o.hi, ncols);
+            const size_t need_p = (size_t)(nsteps + 1) * (size_t)sum_nb * 8;
+            if (series && sum_nb > 0 && need_p * sizeof(double) <= ((size_t)256 << 20) &&
+                persist_groups(num_pc, num_newton, cs_iters) == 0) {
+                if (need_p > partials_cap) {
+                    be.free(d_partials_all);
+                    d_partials_all = nullptr;
+                    partials_cap = 0;
+                    d_partials_all = (double*)be.alloc(need_p * sizeof(double));
+                    partials_cap = need_p;
+                }
+                partials_all = d_partials_all;
+            }
+        }
+        auto norms_of = [&](double tt, int k) {
+            if (!series) return;
+            if (partials_all) {
+                require_state();
+                NormOp op{this, tt, nullptr, false, partials_all + (size_t)k * sum_nb * 8};
+                dispatch(op);
+            } else {
+                error_norms_async(tt, d_series + (size_t)k * 8);
+            }
+        };
         double t = t0;
-        if (series) error_norms_async(t, d_series);
+        norms_of(t, 0);
         for (int k = 0; k < nsteps; ++k) {
             if (integrator == 0)
                 step_feuler(t, dt);
             else
                 step_pc(t, dt, num_pc, num_newton, cs_iters, cs_rtol, sweeps, jtol, jmax);
             t += dt;
-            if (series) error_norms_async(t, d_series + (size_t)(k + 1) * 8);
+            norms_of(t, k + 1);
+        }
+        if constexpr (Backend::kHasPersist) {
+            if (partials_all) be.sums_final_many(partials_all, sum_nb, 8, nsteps + 1, d_series);
         }
         if (series) be.d2h(series, d_series, need_elems * sizeof(double));
         int flag = 0;

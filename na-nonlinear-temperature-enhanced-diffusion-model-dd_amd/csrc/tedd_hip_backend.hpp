@@ -135,8 +135,12 @@ __global__ void __launch_bounds__(256) k_nodes_sum(const F f, int r0, int r1, in
 }
 // one wave per reduced quantity (blockDim = 64 x nr): lane l adds the partials l, l+64, ... in that
 // order, then the lanes are combined by a fixed butterfly -- the same order on every run
+// (a grid of several workgroups finishes several sets of partial sums, one set per workgroup: the sums of the
+// steps of a run, whose final passes are all left to the end of the run)
 __global__ void k_sum_final(const double* partials, int nblocks, int nr, double* out) {
     const int k = threadIdx.y;
+    partials += (size_t)blockIdx.x * nblocks * nr;
+    out += (size_t)blockIdx.x * nr;
     double s = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * nr + k];
     s = wave_sum_fixed(s);
@@ -1004,15 +1008,38 @@ struct HipBackend {
                            (unsigned long long*)dev_out);
         TEDD_HIP(hipGetLastError());
     }
+    // workgroups (= partial sums per quantity) of a sum launch over these rows
+    static int sum_blocks(int r0, int r1, int ncols) {
+        if (r1 <= r0) return 0;
+        int tx, nt, nb;
+        tiling(r0, r1, ncols, tx, nt, nb);
+        return nb;
+    }
+    // the final passes of `count` sum launches whose partial sums lie one set after the other
+    void sums_final_many(const double* partials, int nb, int nr, int count, double* dev_out) {
+        if (count <= 0 || nb <= 0) return;
+        flush_record();
+        hipLaunchKernelGGL(k_sum_final, dim3(count), dim3(64, nr), 0, stream, partials, nb, nr, dev_out);
+        TEDD_HIP(hipGetLastError());
+    }
+    // partials_out (optional): leave the partial sums there and skip the final pass (sums_final_many does it later)
     template <class F>
-    void nodes_sum(int fam, const F& f, int r0, int r1, int ncols, double* dev_out) {
+    void nodes_sum(int fam, const F& f, int r0, int r1, int ncols, double* dev_out, double* partials_out = nullptr) {
         check_range(r0, r1, ncols);
         if (r1 == r0) {
+            if (partials_out) throw std::runtime_error("deferred sums over an empty range");
             memset0(dev_out, F::NR * sizeof(double));
             return;
         }
         int tx, nt, nb;
         tiling(r0, r1, ncols, tx, nt, nb);
+        if (partials_out) {
+            flush_record();
+            Scope sc(this, fam);
+            hipLaunchKernelGGL(k_nodes_sum<F>, dim3(nb), dim3(kTileX, kTileY), 0, stream, f, r0, r1, ncols, tx, nt, partials_out);
+            TEDD_HIP(hipGetLastError());
+            return;
+        }
         if (rec_on) {
             constexpr int kind = IndexOf<F, PSumList>::value;
             if constexpr (kind >= 0) {
