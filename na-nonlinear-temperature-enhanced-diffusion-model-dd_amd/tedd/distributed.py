@@ -84,6 +84,9 @@ class HaloExchange:
         self.slab = slab
         self.group = group
         self._bufs = {}
+        # group ranks of the slabs below and above (a caller with its own rank numbering may set them)
+        self.peer_lo = slab.rank - 1
+        self.peer_hi = slab.rank + 1
         # gloo has no device-memory point-to-point: stage device rows through pinned host buffers
         self.stage_through_host = stage_through_host
 
@@ -115,16 +118,16 @@ class HaloExchange:
             send = self._buf("send_lo", (nf, n_send, pitch), fields[0])
             _copy_many([send[k] for k in range(nf)], [f[o_lo:o_lo + n_send] for f in fields])
             recv = self._buf("recv_lo", (nf, s.ghost_lo, pitch), fields[0])
-            ops.append(dist.P2POp(dist.isend, send, s.rank - 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, recv, s.rank - 1, self.group))
+            ops.append(dist.P2POp(dist.isend, send, self.peer_lo, self.group))
+            ops.append(dist.P2POp(dist.irecv, recv, self.peer_lo, self.group))
             unpack.append((recv, 0, s.ghost_lo))
         if s.rank < s.world - 1:
             n_send = min(s.ghost, s.row_hi)  # = neighbour's ghost_lo
             send = self._buf("send_hi", (nf, n_send, pitch), fields[0])
             _copy_many([send[k] for k in range(nf)], [f[o_hi - n_send:o_hi] for f in fields])
             recv = self._buf("recv_hi", (nf, s.ghost_hi, pitch), fields[0])
-            ops.append(dist.P2POp(dist.isend, send, s.rank + 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, recv, s.rank + 1, self.group))
+            ops.append(dist.P2POp(dist.isend, send, self.peer_hi, self.group))
+            ops.append(dist.P2POp(dist.irecv, recv, self.peer_hi, self.group))
             unpack.append((recv, o_hi, o_hi + s.ghost_hi))
         works = dist.batch_isend_irecv(ops)
         if before_wait is not None:
@@ -142,15 +145,15 @@ class HaloExchange:
             n_send = min(s.ghost, s.n_rows - s.row_lo)
             send = torch.stack([f[o_lo:o_lo + n_send] for f in fields]).cpu()
             recv = torch.empty((len(fields), s.ghost_lo, fields[0].shape[1]), dtype=fields[0].dtype)
-            ops += [dist.P2POp(dist.isend, send, s.rank - 1, self.group),
-                    dist.P2POp(dist.irecv, recv, s.rank - 1, self.group)]
+            ops += [dist.P2POp(dist.isend, send, self.peer_lo, self.group),
+                    dist.P2POp(dist.irecv, recv, self.peer_lo, self.group)]
             unpack.append((recv, 0, s.ghost_lo))
         if s.rank < s.world - 1:
             n_send = min(s.ghost, s.row_hi)
             send = torch.stack([f[o_hi - n_send:o_hi] for f in fields]).cpu()
             recv = torch.empty((len(fields), s.ghost_hi, fields[0].shape[1]), dtype=fields[0].dtype)
-            ops += [dist.P2POp(dist.isend, send, s.rank + 1, self.group),
-                    dist.P2POp(dist.irecv, recv, s.rank + 1, self.group)]
+            ops += [dist.P2POp(dist.isend, send, self.peer_hi, self.group),
+                    dist.P2POp(dist.irecv, recv, self.peer_hi, self.group)]
             unpack.append((recv, o_hi, o_hi + s.ghost_hi))
         works = dist.batch_isend_irecv(ops)
         if before_wait is not None:
