@@ -125,7 +125,12 @@ int tedd_set_mms_program(tedd_ctx* ctx, int32_t which, const uint32_t* code, int
  * workgroup barrier; k > 1: k workgroups and a barrier over the grid -- with the per-sweep solver from zero
  * iterates, bit-identical to "strip_solve" 0 + "warm_start" 0.  Slower than separate launches on every mesh
  * measured on MI355X, hence off; a grid barrier that does not fill within ~0.2 s (compute units held by
- * another program) ends the launch and the next synchronising call returns TEDD_ERR_RUNTIME. */
+ * another program) ends the launch and the next synchronising call returns TEDD_ERR_RUNTIME;
+ * "prog_codegen" (TEDD_MMS_PROGRAM contexts; default -1): the two expression programs are turned into HIP
+ * source, compiled for the context's device at first use (hiprtc; the headers under ../csrc beside the library,
+ * or under $TEDD_CSRC_DIR, are included) and run as ordinary kernels with the program registers in VGPRs --
+ * -1: where that succeeds, the interpreter otherwise; 1: or TEDD_ERR_INVALID with the compiler's message;
+ * 0: interpreter only -- bit-identical arrays either way, about twice the steps per second on a 256^2 mesh. */
 int tedd_set_option(tedd_ctx* ctx, const char* name, double value);
 /* Use the caller's HIP stream (hipStream_t passed as void*) for all subsequent work. */
 int tedd_set_stream(tedd_ctx* ctx, void* hip_stream);

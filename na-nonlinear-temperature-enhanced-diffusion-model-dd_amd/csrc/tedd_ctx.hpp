@@ -151,6 +151,31 @@ public:
         double* d_consts = nullptr;
         int n_ops = 0, n_regs = 0;
     } prog[2];
+    // Programs compiled at run time (backends that have a compiler, tedd_codegen.hpp): -1 use generated kernels and
+    // keep the interpreter if they cannot be built (no compiler library, headers not beside the library), 0
+    // interpreter only, 1 generated kernels or an error.  Same arrays bit for bit either way.
+    HostProg hprog[2];
+    int opt_prog_codegen = -1;
+    int gen_state = 0;  // 0 not tried for the present programs, 1 loaded, -1 failed (gen_error)
+    std::string gen_error;
+    bool gen_now() {
+        if constexpr (!Backend::kHasCodegen) {
+            return false;
+        } else {
+            if (opt_prog_codegen == 0 || !prog[0].d_code || !prog[1].d_code) return false;
+            if (gen_state == 0) {
+                try {
+                    be.gen_load(hprog[0], hprog[1], react);
+                    gen_state = 1;
+                } catch (const std::exception& e) {
+                    gen_state = -1;
+                    gen_error = e.what();
+                }
+            }
+            if (gen_state < 0 && opt_prog_codegen == 1) throw InvalidError(gen_error);
+            return gen_state == 1;
+        }
+    }
     double *d_px = nullptr, *d_py = nullptr, *d_pxq = nullptr, *d_pyq = nullptr;
     int prog_k0 = 0;  // forcing set serving time level 0 of the current call
     int fset[2] = {0, 1};            // which physical array set serves time level 0 / 1
@@ -185,6 +210,11 @@ public:
         // (a constructor that throws runs no destructor: what was allocated so far is released here)
         try {
             be.init(c.device);
+            if constexpr (Backend::kHasPrime) {
+                // large slabs (their ~32 field buffers take 8 GiB or more): see HipBackend::prime_memory
+                const size_t pool = 32 * field_elems() * sizeof(double);
+                if (pool >= ((size_t)8 << 30)) be.prime_memory(pool);
+            }
             set_model(c.consts, c.model_kind, c.eta, c.mms_params);
             build_geometry();
             build_mms_tables();
@@ -385,6 +415,11 @@ public:
         if (n_consts > 0) be.h2d(q.d_consts, consts, (size_t)n_consts * sizeof(double));
         q.n_ops = n_ops;
         q.n_regs = n_regs;
+        hprog[which].code.assign(code, code + n_ops);
+        hprog[which].consts.assign(consts, consts + (n_consts > 0 ? n_consts : 0));
+        hprog[which].n_regs = n_regs;
+        gen_state = 0;
+        if constexpr (Backend::kHasCodegen) be.gen_unload();
         fset_time[0] = fset_time[1] = NAN;
         if (!d_px) build_prog_axes();
     }
@@ -429,14 +464,29 @@ public:
     void prog_exact(double t, double* const out[5], int what) {
         Out5 o;
         for (int v = 0; v < 5; ++v) o.v[v] = out[v];
-        ProgExactFn f{grid(), program(0), prog_axes(), t, o, what};
-        be.nodes_prog(FAM_MISC, f, 0, nrows, ncols, prog[0].n_regs);
+        bool generated = false;
+        if constexpr (Backend::kHasCodegen) {
+            if (gen_now()) {
+                be.gen_exact(FAM_MISC, grid(), prog_axes(), t, o, what, 0, nrows, ncols);
+                generated = true;
+            }
+        }
+        if (!generated) {
+            ProgExactFn f{grid(), program(0), prog_axes(), t, o, what};
+            be.nodes_prog(FAM_MISC, f, 0, nrows, ncols, prog[0].n_regs);
+        }
         for (int v = 0; v < 5; ++v) mark(out[v], full());
     }
     template <int REACT>
     void prog_forcing(double t, double* const out[5]) {
         Out5 o;
         for (int v = 0; v < 5; ++v) o.v[v] = out[v];
+        if constexpr (Backend::kHasCodegen) {
+            if (gen_now()) {  // (compiled for this context's reaction kind, which REACT is)
+                be.gen_forcing(FAM_FORCING, grid(), model, prog_axes(), t, o, 0, nrows, ncols);
+                return;
+            }
+        }
         ProgForcingFn<REACT> f{grid(), model, program(0), program(1), prog_axes(), t, o};
         be.nodes_prog(FAM_FORCING, f, 0, nrows, ncols, std::max(prog[0].n_regs, prog[1].n_regs));
     }
@@ -1779,6 +1829,8 @@ public:
         } else if (name == "persistent") {
             opt_persistent = (int)value;
             bT_ready = false;
+        } else if (name == "prog_codegen") {
+            opt_prog_codegen = value < 0.0 ? -1 : (value != 0.0);
         } else if (name == "warm_start") {
             opt_warm = value != 0.0;
             if (!opt_warm) drop_prev();

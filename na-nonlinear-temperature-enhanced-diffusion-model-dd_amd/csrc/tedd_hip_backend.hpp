@@ -5,6 +5,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
@@ -16,6 +18,7 @@
 
 #include "tedd_strip.hpp"
 #include "tedd_march.hpp"
+#include "tedd_codegen.hpp"
 #include "tedd_ctx.hpp"
 
 namespace tedd {
@@ -576,6 +579,7 @@ struct HipBackend {
     }
     void shutdown() {
         if (stream) (void)hipStreamSynchronize(stream);
+        gen_unload();
         for (Rec& r : recs) {
             (void)hipEventDestroy(r.a);
             (void)hipEventDestroy(r.b);
@@ -648,6 +652,34 @@ struct HipBackend {
             ptr[dev] = p;
         }
         return ptr[dev];
+    }
+    // Device memory that has been handed out, written and returned once before serves the streaming launches of
+    // a large slab faster than the memory the first process on a freshly started machine is given: on an MI355X
+    // the predictor of a 16384^2 mesh takes 9.2 ms per launch in such a first process, for the whole life of its
+    // context, and 8.3-8.8 ms in every later process, or in the first one after 100 GiB were allocated, zeroed
+    // and freed (0.2 s); the whole step 34.4 against 33.4 ms.  (The cause lies below the HIP interface -- which
+    // physical pages the driver hands out -- and was not found; staggered or spaced field addresses change
+    // nothing.)  So a context that is about to allocate a large pool takes that much memory once, writes it and
+    // gives it back.  TEDD_PRIME_MEMORY=0 in the environment skips it; a failure here is not an error.
+    static constexpr bool kHasPrime = true;
+    void prime_memory(size_t bytes) {
+        const char* e = std::getenv("TEDD_PRIME_MEMORY");
+        if (e && e[0] == '0') return;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        bytes = std::min(bytes, fr - fr / 8);
+        void* p = nullptr;
+        if (bytes == 0 || hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        (void)hipMemsetAsync(p, 0, bytes, stream);
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(p);
+        (void)hipGetLastError();
     }
     void* alloc(size_t bytes) {
         void* p = nullptr;
@@ -967,6 +999,47 @@ struct HipBackend {
         else
             hipLaunchKernelGGL((k_forcing_columns<F, 2>), dim3(tiles_x, tiles_y), dim3(256), 0, stream, f, r0, r1, ncols, seg);
         TEDD_HIP(hipGetLastError());
+    }
+    // ---- expression programs compiled at run time (tedd_codegen.hpp)
+    static constexpr bool kHasCodegen = true;
+    hipModule_t gen_mod = nullptr;
+    hipFunction_t gen_forcing_fn = nullptr, gen_exact_fn = nullptr;
+    void gen_unload() {
+        if (gen_mod) (void)hipModuleUnload(gen_mod);
+        gen_mod = nullptr;
+        gen_forcing_fn = gen_exact_fn = nullptr;
+    }
+    bool gen_ready() const { return gen_mod != nullptr; }
+    void gen_load(const HostProg& node, const HostProg& cell, int react) {
+        gen_unload();
+        hipDeviceProp_t pr;
+        TEDD_HIP(hipGetDeviceProperties(&pr, device));
+        const std::vector<char>& code = gen_compile(gen_source(node, cell, react), pr.gcnArchName);
+        TEDD_HIP(hipModuleLoadData(&gen_mod, code.data()));
+        hipError_t e = hipModuleGetFunction(&gen_forcing_fn, gen_mod, "tedd_gen_forcing");
+        if (e == hipSuccess) e = hipModuleGetFunction(&gen_exact_fn, gen_mod, "tedd_gen_exact");
+        if (e != hipSuccess) {
+            gen_unload();
+            TEDD_HIP(e);
+        }
+    }
+    void gen_launch(int fam, hipFunction_t fn, void** args, int r0, int r1, int ncols) {
+        check_range(r0, r1, ncols);
+        if (r1 == r0) return;
+        if (!fn) throw std::runtime_error("generated MMS kernels are not loaded");
+        if ((r1 - r0 + 3) / 4 > 65535) throw std::runtime_error("slab too tall for the program launch");
+        flush_record();
+        Scope sc(this, fam);
+        TEDD_HIP(hipModuleLaunchKernel(fn, (unsigned)((ncols + 63) / 64), (unsigned)((r1 - r0 + 3) / 4), 1, 64, 4, 1, 0, stream,
+                                       args, nullptr));
+    }
+    void gen_forcing(int fam, GridDev g, ModelC m, ProgAxes ax, double t, Out5 out, int r0, int r1, int ncols) {
+        void* args[] = {&g, &m, &ax, &t, &out, &r0, &r1};
+        gen_launch(fam, gen_forcing_fn, args, r0, r1, ncols);
+    }
+    void gen_exact(int fam, GridDev g, ProgAxes ax, double t, Out5 out, int what, int r0, int r1, int ncols) {
+        void* args[] = {&g, &ax, &t, &out, &what, &r0, &r1};
+        gen_launch(fam, gen_exact_fn, args, r0, r1, ncols);
     }
     template <class F>
     void nodes_prog(int fam, const F& f, int r0, int r1, int ncols, int n_regs) {

@@ -11,8 +11,21 @@
 //   MMS forcing           prob1base.py:2313-2425, 3503-3551
 //   MMS exact solutions   prob1_mms_cases.py:151-337, 406-511
 #pragma once
+// (the run-time compiler brings its own declarations of the math functions and fixed-width integers)
+#if !defined(__HIPCC_RTC__)
 #include <cmath>
 #include <cstdint>
+#else
+#ifndef INFINITY
+#define INFINITY __builtin_huge_val()
+#endif
+#ifndef NAN
+#define NAN __builtin_nan("")
+#endif
+using __hip_internal::int8_t;
+using __hip_internal::uint32_t;
+using __hip_internal::uint64_t;
+#endif
 
 #if defined(__HIPCC__)
 #define TEDD_HD __host__ __device__ __forceinline__

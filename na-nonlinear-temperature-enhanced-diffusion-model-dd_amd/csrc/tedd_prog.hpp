@@ -19,8 +19,12 @@
 // The registers of a thread live in LDS (one column per lane, so register k of all lanes is one
 // conflict-free row), because a register file indexed by program words cannot live in VGPRs.
 #pragma once
+// (the run-time compiler brings its own declarations of the math functions and fixed-width integers)
+#if !defined(__HIPCC_RTC__)
 #include <cmath>
 #include <cstdint>
+#include <vector>
+#endif
 
 #include "tedd_nodes.hpp"
 
@@ -39,6 +43,15 @@ struct MmsProg {
     const double* consts;
     int n_ops;
 };
+
+#if !defined(__HIPCC_RTC__)
+// host copy of a validated program (what the run-time code generator reads)
+struct HostProg {
+    std::vector<uint32_t> code;
+    std::vector<double> consts;
+    int n_regs = 0;
+};
+#endif
 
 // reg[k] of this thread is regs[k * stride]
 TEDD_HD void prog_run(const MmsProg& P, double* regs, int stride, double t, double x, double y, double* out) {
@@ -100,7 +113,73 @@ struct ProgAxes {
     int nrows, ld;
 };
 
-// Exact solution (or one kind of derivative) at the nodes: same output convention as ExactFn.
+// How a thread evaluates the two programs.  ProgInterp runs the words (registers in LDS or, on the host, in a
+// small array); source generated from the words at run time (tedd_codegen.hpp) defines its own evaluator with
+// the same two members, the programs spelled out as straight-line code.
+struct ProgInterp {
+    MmsProg node_p, cell_p;
+    double* regs;
+    int stride;
+    TEDD_HD void node(double t, double x, double y, double* out) const { prog_run(node_p, regs, stride, t, x, y, out); }
+    TEDD_HD void cell(double t, double x, double y, double* out) const { prog_run(cell_p, regs, stride, t, x, y, out); }
+};
+
+// Exact solution (or one kind of derivative) at a node: same output convention as ExactFn.
+template <class Eval>
+TEDD_HD void prog_exact_node(const Eval& ev, const GridDev& g, const ProgAxes& ax, double t, const Out5& out, int what, int li,
+                             int j) {
+    double p[kProgNodeOutputs];
+    ev.node(t, ax.x[li], ax.y[j], p);
+    const size_t c = at(g, li, j);
+    const double nan = NAN;
+    double r[5];
+    switch (what) {
+        case 1: r[0] = p[1]; r[1] = p[5]; r[2] = p[10]; r[3] = p[15]; r[4] = p[20]; break;
+        case 2: r[0] = p[2]; r[1] = p[6]; r[2] = p[11]; r[3] = p[16]; r[4] = nan; break;
+        case 3: r[0] = p[3]; r[1] = p[7]; r[2] = p[12]; r[3] = p[17]; r[4] = nan; break;
+        case 4: r[0] = nan; r[1] = p[8]; r[2] = p[13]; r[3] = p[18]; r[4] = nan; break;
+        default: r[0] = p[0]; r[1] = p[4]; r[2] = p[9]; r[3] = p[14]; r[4] = p[19]; break;
+    }
+    for (int v = 0; v < 5; ++v) out.v[v][c] = r[v];
+}
+
+// The five forcing values of a node at one time: nodal fT, fcl, fcd, fcs from the node program through the same
+// formulas as the closed-form cases (mms_fT ... mms_fcs_gain), fcp as the 3x3 Gauss cell average of the
+// pointwise cp-forcing from the cell program (0 on the boundary).
+template <int REACT, class Eval>
+TEDD_HD void prog_forcing_node(const Eval& ev, const GridDev& g, const ModelC& m, const ProgAxes& ax, double t, const Out5& out,
+                               int li, int j) {
+    double q[kProgNodeOutputs];
+    ev.node(t, ax.x[li], ax.y[j], q);
+    MmsPt p;
+    p.cp = q[0]; p.cp_t = q[1]; p.cp_x = q[2]; p.cp_y = q[3];
+    p.T = q[4]; p.T_t = q[5]; p.T_x = q[6]; p.T_y = q[7]; p.T_l = q[8];
+    p.cl = q[9]; p.cl_t = q[10]; p.cl_x = q[11]; p.cl_y = q[12]; p.cl_l = q[13];
+    p.cd = q[14]; p.cd_t = q[15]; p.cd_x = q[16]; p.cd_y = q[17]; p.cd_l = q[18];
+    p.cs = q[19]; p.cs_t = q[20];
+    const size_t c = at(g, li, j);
+    const double gain = reaction_gain<REACT>(m, p.cs);
+    out.v[1][c] = mms_fT(m, p);
+    out.v[2][c] = mms_fcl(m, p);
+    out.v[3][c] = mms_fcd_gain(m, p, gain);
+    out.v[4][c] = mms_fcs_gain(m, p, gain);
+    double fcp = 0.0;
+    if (is_interior(g, li, j)) {
+        const double w[3] = {5.0 / 9.0, 8.0 / 9.0, 5.0 / 9.0};
+        double acc = 0.0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                double u[kProgCellOutputs];
+                ev.cell(t, ax.xq[a * ax.nrows + li], ax.yq[b * ax.ld + j], u);
+                const double cp = u[0], cp_t = u[1], cl = u[2], T = u[3];
+                acc += w[a] * w[b] * (cp_t - (-cp * (m.K1 * (1.0 + cl) + m.K2 * T)));
+            }
+        fcp = 0.25 * acc;
+    }
+    out.v[0][c] = fcp;
+}
+
+// the interpreting node functors
 struct ProgExactFn {
     GridDev g;
     MmsProg P;
@@ -109,25 +188,9 @@ struct ProgExactFn {
     Out5 out;
     int what;
     TEDD_HD void operator()(int li, int j, double* regs, int stride) const {
-        double p[kProgNodeOutputs];
-        prog_run(P, regs, stride, t, ax.x[li], ax.y[j], p);
-        const size_t c = at(g, li, j);
-        const double nan = NAN;
-        double r[5];
-        switch (what) {
-            case 1: r[0] = p[1]; r[1] = p[5]; r[2] = p[10]; r[3] = p[15]; r[4] = p[20]; break;
-            case 2: r[0] = p[2]; r[1] = p[6]; r[2] = p[11]; r[3] = p[16]; r[4] = nan; break;
-            case 3: r[0] = p[3]; r[1] = p[7]; r[2] = p[12]; r[3] = p[17]; r[4] = nan; break;
-            case 4: r[0] = nan; r[1] = p[8]; r[2] = p[13]; r[3] = p[18]; r[4] = nan; break;
-            default: r[0] = p[0]; r[1] = p[4]; r[2] = p[9]; r[3] = p[14]; r[4] = p[19]; break;
-        }
-        for (int v = 0; v < 5; ++v) out.v[v][c] = r[v];
+        prog_exact_node(ProgInterp{P, P, regs, stride}, g, ax, t, out, what, li, j);
     }
 };
-
-// The five forcing arrays at one time: nodal fT, fcl, fcd, fcs from the node program through the same
-// formulas as the closed-form cases (mms_fT ... mms_fcs_gain), fcp as the 3x3 Gauss cell average of the
-// pointwise cp-forcing from the cell program (0 on the boundary).
 template <int REACT>
 struct ProgForcingFn {
     GridDev g;
@@ -137,34 +200,7 @@ struct ProgForcingFn {
     double t;
     Out5 out;
     TEDD_HD void operator()(int li, int j, double* regs, int stride) const {
-        double q[kProgNodeOutputs];
-        prog_run(node, regs, stride, t, ax.x[li], ax.y[j], q);
-        MmsPt p;
-        p.cp = q[0]; p.cp_t = q[1]; p.cp_x = q[2]; p.cp_y = q[3];
-        p.T = q[4]; p.T_t = q[5]; p.T_x = q[6]; p.T_y = q[7]; p.T_l = q[8];
-        p.cl = q[9]; p.cl_t = q[10]; p.cl_x = q[11]; p.cl_y = q[12]; p.cl_l = q[13];
-        p.cd = q[14]; p.cd_t = q[15]; p.cd_x = q[16]; p.cd_y = q[17]; p.cd_l = q[18];
-        p.cs = q[19]; p.cs_t = q[20];
-        const size_t c = at(g, li, j);
-        const double gain = reaction_gain<REACT>(m, p.cs);
-        out.v[1][c] = mms_fT(m, p);
-        out.v[2][c] = mms_fcl(m, p);
-        out.v[3][c] = mms_fcd_gain(m, p, gain);
-        out.v[4][c] = mms_fcs_gain(m, p, gain);
-        double fcp = 0.0;
-        if (is_interior(g, li, j)) {
-            const double w[3] = {5.0 / 9.0, 8.0 / 9.0, 5.0 / 9.0};
-            double acc = 0.0;
-            for (int a = 0; a < 3; ++a)
-                for (int b = 0; b < 3; ++b) {
-                    double u[kProgCellOutputs];
-                    prog_run(cell, regs, stride, t, ax.xq[a * ax.nrows + li], ax.yq[b * ax.ld + j], u);
-                    const double cp = u[0], cp_t = u[1], cl = u[2], T = u[3];
-                    acc += w[a] * w[b] * (cp_t - (-cp * (m.K1 * (1.0 + cl) + m.K2 * T)));
-                }
-            fcp = 0.25 * acc;
-        }
-        out.v[0][c] = fcp;
+        prog_forcing_node<REACT>(ProgInterp{node, cell, regs, stride}, g, m, ax, t, out, li, j);
     }
 };
 

@@ -252,11 +252,10 @@ def check_prefetch_forcing():
 
 
 # ---------------------------------------------------------------------------------- expression programs
-def check_mms_program(react):
-    """TEDD_MMS_PROGRAM through the C ABI: the exact solution, its derivatives, the five forcing arrays
-    and a few steps from programs lowered from the expressions of the ExpSin case (reference
-    src/prob1_mms_cases.py:280-337, here with the time integrals written out) equal the library's
-    closed-form ExpSin case; malformed programs are refused."""
+def expsin_programs():
+    """Mesh, model constants and the node / cell programs lowered from the expressions of the ExpSin case
+    (reference src/prob1_mms_cases.py:280-337, the time integrals written out) on a non-uniform mesh with
+    exaggerated model constants."""
     sympy = pytest.importorskip("sympy")
     from tedd import _symprog as sp
     z = load("golden_mms.npz")
@@ -279,6 +278,16 @@ def check_mms_program(react):
         named.update({name: e, "dt_" + name: sympy.diff(e, t), "dx_" + name: dx, "dy_" + name: dy,
                       "lap_" + name: sympy.diff(dx, X) + sympy.diff(dy, Y)})
     node, cell = sp.lower_case(named, t, X, Y)
+    return x, y, consts, node, cell
+
+
+def check_mms_program(react):
+    """TEDD_MMS_PROGRAM through the C ABI: the exact solution, its derivatives, the five forcing arrays
+    and a few steps from programs lowered from the expressions of the ExpSin case (reference
+    src/prob1_mms_cases.py:280-337, here with the time integrals written out) equal the library's
+    closed-form ExpSin case; malformed programs are refused."""
+    from tedd import _symprog as sp
+    x, y, consts, node, cell = expsin_programs()
     kw = dict(model_kind=2, reaction_kind=REACT_OF[react], eta=50.0 if react == "reg" else 0.0)
     prog = _ffi.Context(x, y, consts, mms_case=_ffi.MMS_PROGRAM, **kw)
     ref = _ffi.Context(x, y, consts, mms_case=_ffi.MMS_EXPSIN, **kw)
@@ -321,6 +330,75 @@ def check_mms_program(react):
         ref.set_mms_program(0, *node)  # not a program context
     prog.close()
     ref.close()
+
+
+def all_ops_programs():
+    """Programs whose expressions use every operation of the program format (powers with integer, negative and
+    real exponents, exp, sin, cos, sqrt, log, abs, sign, tanh, division)."""
+    sympy = pytest.importorskip("sympy")
+    from tedd import _symprog as sp
+    t, X, Y = sympy.symbols("t x y", real=True)
+    cp = sympy.tanh(X * Y) + sympy.sqrt(1 + t + X) / (2 + Y)
+    # (abs only of the time: its time derivative is a sign, and no derivative of a sign is asked for)
+    T = sympy.log(2 + X * Y + t) * sympy.cos(3 * X) - sympy.Abs(t - sympy.Rational(1, 3)) * X * Y
+    cl = (1 + X) ** sympy.Rational(5, 2) * sympy.exp(-t) + (Y - sympy.Rational(2, 5)) ** 4
+    cd = (1 + X * X + Y) ** (-2) + sympy.sin(t + Y) ** 5
+    cs = sympy.Rational(1, 10) + (X * (1 - X) * Y * (1 - Y)) ** 2 / (1 + t) ** 3
+    named = {}
+    for name, e in {"cp": cp, "T": T, "cl": cl, "cd": cd, "cs": cs}.items():
+        dx, dy = sympy.diff(e, X), sympy.diff(e, Y)
+        named.update({name: e, "dt_" + name: sympy.diff(e, t), "dx_" + name: dx, "dy_" + name: dy,
+                      "lap_" + name: sympy.diff(dx, X) + sympy.diff(dy, Y)})
+    node, cell = sp.lower_case(named, t, X, Y)
+    used = {int(w) & 0xff for w in node[0]} | {int(w) & 0xff for w in cell[0]}
+    for op in ("OP_ADD", "OP_SUB", "OP_MUL", "OP_DIV", "OP_POWI", "OP_POW", "OP_EXP", "OP_SIN", "OP_COS", "OP_SQRT",
+               "OP_LOG", "OP_ABS", "OP_SIGN", "OP_TANH"):
+        assert getattr(sp, op) in used, op
+    return node, cell
+
+
+def check_generated_kernels_equal_interpreter(react, which):
+    """The expression programs compiled at run time (option prog_codegen = 1: generated kernels or an error)
+    produce, bit for bit, the arrays of the interpreter (prog_codegen = 0): exact solution and derivatives,
+    forcing arrays, states and error norms after a few steps."""
+    if which == "expsin":
+        x, y, consts, node, cell = expsin_programs()
+    else:
+        x, y, consts, _, _ = expsin_programs()
+        node, cell = all_ops_programs()
+    kw = dict(model_kind=2, reaction_kind=REACT_OF[react], eta=50.0 if react == "reg" else 0.0)
+    ctxs = []
+    for codegen in (1, 0):
+        c = _ffi.Context(x, y, consts, mms_case=_ffi.MMS_PROGRAM, **kw)
+        c.set_option("prog_codegen", codegen)
+        c.set_mms_program(0, *node)
+        c.set_mms_program(1, *cell)
+        ctxs.append(c)
+    gen, interp = ctxs
+    for tt in (0.0, 0.37):
+        for what in range(5):
+            for p_, r_ in zip(gen.eval_mms(tt, what), interp.eval_mms(tt, what)):
+                np.testing.assert_array_equal(p_, r_)
+        for p_, r_ in zip(gen.eval_forcing(tt), interp.eval_forcing(tt)):
+            assert np.all(np.isfinite(r_))
+            np.testing.assert_array_equal(p_, r_)
+    for c in ctxs:
+        c.set_state_exact(0.0)
+    ea = gen.advance(0.0, 0.01, 3, integrator=1)
+    eb = interp.advance(0.0, 0.01, 3, integrator=1)
+    np.testing.assert_array_equal(ea, eb)
+    for p_, r_ in zip(gen.get_state(), interp.get_state()):
+        np.testing.assert_array_equal(p_, r_)
+    # new programs replace the compiled ones
+    x2, y2, consts2, node2, cell2 = expsin_programs()
+    gen.set_mms_program(0, *node2)
+    gen.set_mms_program(1, *cell2)
+    interp.set_mms_program(0, *node2)
+    interp.set_mms_program(1, *cell2)
+    for p_, r_ in zip(gen.eval_forcing(0.2), interp.eval_forcing(0.2)):
+        np.testing.assert_array_equal(p_, r_)
+    for c in ctxs:
+        c.close()
 
 
 # ---------------------------------------------------------------------------------- sub-steps

@@ -17,6 +17,8 @@ namespace tedd {
 struct CpuBackend {
     static constexpr bool kHasStripSolve = false;
     static constexpr bool kHasPersist = false;
+    static constexpr bool kHasPrime = false;
+    static constexpr bool kHasCodegen = false;
     void rec_begin(int, int) {}
     void rec_end() {}
     void rec_discard() noexcept {}

@@ -148,6 +148,13 @@ def test_mms_program_equals_closed_form(react):
     cc.check_mms_program(react)
 
 
+# ---- the same programs compiled at run time (hiprtc) instead of interpreted
+@pytest.mark.parametrize("which", ["expsin", "all_ops"])
+@pytest.mark.parametrize("react", ["reg", "cs3", "hcs"])
+def test_generated_program_kernels_equal_interpreter(react, which):
+    cc.check_generated_kernels_equal_interpreter(react, which)
+
+
 # ---- the pieces of a predictor-corrector step called on their own
 @pytest.mark.parametrize("streamed", [False, True], ids=["closed_form", "streamed"])
 @pytest.mark.parametrize("tag", cc.tags("golden_substeps.npz", "/t0"))

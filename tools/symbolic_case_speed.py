@@ -14,6 +14,17 @@ import tedd.prob1base as p1
 from api_cases import model_of
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+# second argument: library option prog_codegen for every program context (1 kernels compiled at run time or an
+# error, 0 interpreter, default -1: compiled where possible)
+if len(sys.argv) > 2:
+    from tedd import _ffi
+    _mode, _orig = float(sys.argv[2]), _ffi.Context.set_mms_program
+
+    def _set_program(self, which, *a):
+        self.set_option("prog_codegen", _mode)
+        return _orig(self, which, *a)
+    _ffi.Context.set_mms_program = _set_program
+    print("prog_codegen =", _mode)
 model = model_of("nb_b")
 grid = p1.make_uniform_grid(N, N)
 u = p1.x_sym * (1 - p1.x_sym) * p1.y_sym * (1 - p1.y_sym) / (1 + p1.t_sym)
