@@ -134,6 +134,52 @@ inline std::string gen_include_dir() {
                              "it (../csrc) nor under TEDD_CSRC_DIR");
 }
 
+// The run-time compiler is loaded when the first program is compiled, not when the library is: a machine without
+// it keeps the interpreter (and everything that is not an expression program).
+struct HiprtcApi {
+    decltype(&hiprtcCreateProgram) create = nullptr;
+    decltype(&hiprtcCompileProgram) compile = nullptr;
+    decltype(&hiprtcGetProgramLogSize) log_size = nullptr;
+    decltype(&hiprtcGetProgramLog) log = nullptr;
+    decltype(&hiprtcGetCodeSize) code_size = nullptr;
+    decltype(&hiprtcGetCode) code = nullptr;
+    decltype(&hiprtcDestroyProgram) destroy = nullptr;
+    decltype(&hiprtcGetErrorString) error_string = nullptr;
+    // (call with the compile mutex held)
+    static const HiprtcApi& get() {
+        static HiprtcApi api;
+        static bool tried = false;
+        static std::string why;
+        if (!tried) {
+            tried = true;
+            void* h = nullptr;
+            for (const char* name : {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (h) break;
+            }
+            if (!h) {
+                why = "generated MMS kernels: the run-time compiler library (libhiprtc.so) could not be loaded";
+            } else {
+                auto sym = [&](const char* n) {
+                    void* p = dlsym(h, n);
+                    if (!p && why.empty()) why = std::string("generated MMS kernels: libhiprtc.so lacks ") + n;
+                    return p;
+                };
+                api.create = reinterpret_cast<decltype(api.create)>(sym("hiprtcCreateProgram"));
+                api.compile = reinterpret_cast<decltype(api.compile)>(sym("hiprtcCompileProgram"));
+                api.log_size = reinterpret_cast<decltype(api.log_size)>(sym("hiprtcGetProgramLogSize"));
+                api.log = reinterpret_cast<decltype(api.log)>(sym("hiprtcGetProgramLog"));
+                api.code_size = reinterpret_cast<decltype(api.code_size)>(sym("hiprtcGetCodeSize"));
+                api.code = reinterpret_cast<decltype(api.code)>(sym("hiprtcGetCode"));
+                api.destroy = reinterpret_cast<decltype(api.destroy)>(sym("hiprtcDestroyProgram"));
+                api.error_string = reinterpret_cast<decltype(api.error_string)>(sym("hiprtcGetErrorString"));
+            }
+        }
+        if (!why.empty()) throw std::runtime_error(why);
+        return api;
+    }
+};
+
 // compiled code object of a source text for an architecture (cached per process)
 inline const std::vector<char>& gen_compile(const std::string& src, const std::string& arch) {
     static std::mutex mu;
@@ -142,34 +188,35 @@ inline const std::vector<char>& gen_compile(const std::string& src, const std::s
     const std::string key = arch + "\n" + src;
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
+    const HiprtcApi& rtc = HiprtcApi::get();
     const std::string inc = "-I" + gen_include_dir();
     const std::string march = "--offload-arch=" + arch;
     hiprtcProgram prog = nullptr;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "tedd_generated_mms.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+    if (rtc.create(&prog, src.c_str(), "tedd_generated_mms.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         throw std::runtime_error("generated MMS kernels: hiprtcCreateProgram failed");
     // -ffp-contract=on as the library itself: a multiply and an add fuse only inside one source expression
     const char* opts[] = {march.c_str(), "-O3", "-std=c++17", "-ffp-contract=on", inc.c_str()};
-    const hiprtcResult rc = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+    const hiprtcResult rc = rtc.compile(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
     if (rc != HIPRTC_SUCCESS) {
         size_t n = 0;
         std::string log;
-        if (hiprtcGetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n > 1) {
+        if (rtc.log_size(prog, &n) == HIPRTC_SUCCESS && n > 1) {
             log.resize(n);
-            (void)hiprtcGetProgramLog(prog, &log[0]);
+            (void)rtc.log(prog, &log[0]);
         }
-        (void)hiprtcDestroyProgram(&prog);
+        (void)rtc.destroy(&prog);
         if (log.size() > 1500) log.resize(1500);
-        throw std::runtime_error(std::string("generated MMS kernels: compilation failed: ") + hiprtcGetErrorString(rc) + "\n" + log);
+        throw std::runtime_error(std::string("generated MMS kernels: compilation failed: ") + rtc.error_string(rc) + "\n" + log);
     }
     size_t size = 0;
     std::vector<char> code;
-    if (hiprtcGetCodeSize(prog, &size) != HIPRTC_SUCCESS || size == 0) {
-        (void)hiprtcDestroyProgram(&prog);
+    if (rtc.code_size(prog, &size) != HIPRTC_SUCCESS || size == 0) {
+        (void)rtc.destroy(&prog);
         throw std::runtime_error("generated MMS kernels: empty code object");
     }
     code.resize(size);
-    const hiprtcResult rc2 = hiprtcGetCode(prog, code.data());
-    (void)hiprtcDestroyProgram(&prog);
+    const hiprtcResult rc2 = rtc.code(prog, code.data());
+    (void)rtc.destroy(&prog);
     if (rc2 != HIPRTC_SUCCESS) throw std::runtime_error("generated MMS kernels: hiprtcGetCode failed");
     return cache.emplace(key, std::move(code)).first->second;
 }
