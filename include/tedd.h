@@ -113,7 +113,9 @@ int tedd_set_mms_program(tedd_ctx* ctx, int32_t which, const uint32_t* code, int
  * slabs of at least 2^25 nodes; 0 never, 1 always): the predictor and the right-hand sides of the cl and cd
  * systems run in the marching launcher (a wavefront walks down 64 columns with the stencil rows in registers:
  * every array row is read once) instead of one thread per node -- bit-identical results; "march_rows",
- * "march_occ": rows per segment and waves per SIMD of that launcher (0: the kernel's own choice);
+ * "march_occ": rows per segment and waves per SIMD of that launcher (0: the kernel's own choice); "march_lds"
+ * (default -1: the right-hand sides; 0 never): a marching launch without look-ahead in registers has the next
+ * row written into LDS by the load unit while it computes the present one -- bit-identical results;
  * "forcing_columns" (default 1): the forcing arrays of a closed-form case are made by threads that walk down
  * columns with the column's table entries in registers, on slabs large enough to fill the GPU that way
  * (0: one thread per node everywhere) -- bit-identical results; "strip_panel" (default 8; 0: row-major):

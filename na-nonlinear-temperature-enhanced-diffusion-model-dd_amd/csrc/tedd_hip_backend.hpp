@@ -439,6 +439,7 @@ struct HipBackend {
     // launcher's many small workgroups fill the GPU better), 0 never, 1 always
     int opt_march = -1;
     int opt_march_rows = 0;  // rows per segment (0: per functor, fewer on slabs with few rows)
+    int opt_march_lds = -1;       // marching kernels without look-ahead in registers prefetch through LDS (-1: per functor)
     int opt_march_ahead = -1;     // marching kernels request the next row a row ahead (-1: per functor)
     int opt_strip_panel = 8;      // tile rows per panel of the strip launches' tile order (0: row-major)
     int opt_forcing_columns = 1;  // forcing arrays by column-walking threads (0: one thread per node)
@@ -951,6 +952,20 @@ struct HipBackend {
                 // the kernel: 2 waves per SIMD with the next row requested a row ahead, 3 and 4 without.
                 const int occ = opt_march_occ > 0 ? opt_march_occ : F::kMarchOcc;
                 const bool ahead = opt_march_ahead >= 0 ? opt_march_ahead != 0 : (occ <= 2 || F::kMarchAhead);
+                if constexpr (F::kMarchLds) {
+                    if (opt_march_lds != 0 && !ahead) {
+                        // (two builds per functor: its own number of waves per SIMD and one fewer)
+                        constexpr int K = F::kMarchOcc;
+                        if (occ < K)
+                            hipLaunchKernelGGL((k_march_lds<F, K - 1>), dim3((unsigned)nt), dim3(64, kMarchWaves), 0, stream, f, r0,
+                                               r1, ncols, seg, tiles_x);
+                        else
+                            hipLaunchKernelGGL((k_march_lds<F, K>), dim3((unsigned)nt), dim3(64, kMarchWaves), 0, stream, f, r0, r1,
+                                               ncols, seg, tiles_x);
+                        TEDD_HIP(hipGetLastError());
+                        return;
+                    }
+                }
                 auto go = [&](auto occ_c, auto ahead_c) {
                     hipLaunchKernelGGL((k_march<F, decltype(occ_c)::value, decltype(ahead_c)::value>), dim3((unsigned)nt),
                                        dim3(64, kMarchWaves), 0, stream, f, r0, r1, ncols, seg, tiles_x);

@@ -147,4 +147,138 @@ k_march(const F f, int r0, int r1, int ncols, int seg_rows, int tiles_x) {
     }
 }
 
+// The same march with the next row's loads travelling into LDS instead of into registers.
+//
+// The functors that run at three or four waves per SIMD have no registers to hold a row that is still on its
+// way, so in k_march they ask for row li+1 at the top of row li and wait for it there: one memory round trip per
+// row, hidden only by the other waves of the SIMD.  Here a wave owns two slots of LDS and asks for everything
+// row li+1 will need while it computes row li, with loads that write straight into LDS (16 bytes per lane, lane
+// l at byte 16 l of the destination: global_load_lds_dwordx4): of every stencil array the 64 doubles of its
+// columns in row li+2 -- lanes 1..32 -- and, as lanes 0 and 33, the two granules that hold columns -1 and 64 of
+// row li+1 (the row that will then be the centre: what lanes 0 and 63 need from outside the wave); of the arrays
+// read at the node alone, two per instruction, the 64 doubles of row li+1.  At the top of the next row the wave
+// waits for that one batch, reads it from LDS (consecutive lanes, consecutive doubles: no bank conflicts) and
+// asks for the next.  Registers as in k_march without look-ahead; LDS 2 x (68 NS + 64 NC) doubles per wave.
+// Same node bodies on the same values: bit-identical results.
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* global_void_ptr;
+
+template <class F, int OCC>
+__global__ void __launch_bounds__(64 * kMarchWaves) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
+k_march_lds(const F f, int r0, int r1, int ncols, int seg_rows, int tiles_x) {
+    constexpr int NS = F::NS, NC = F::NC;
+    constexpr int kSlot = 68 * NS + 64 * NC;  // doubles
+    __shared__ __attribute__((aligned(16))) double ring[kMarchWaves][2][kSlot];
+    const GridDev& g = f.g;
+    const int lane = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q = nb / 8, rem = nb % 8, xcd = bid % 8;
+    const int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
+    const int ty = t / tiles_x, tx = t % tiles_x;
+
+    const int col0 = (tx * kMarchWaves + wave) * 64;
+    const int j = col0 + lane;
+    const int ra = r0 + ty * seg_rows;
+    const int rb = min(ra + seg_rows, r1);
+    if (col0 >= ncols) return;  // (whole wave out of the mesh)
+    const bool col_ok = j < ncols;
+    const unsigned jc = (unsigned)min(j, ncols - 1);
+    const int rmax = g.nrows - 1;
+    const double rks = g.rk[jc], rkn = g.rk[min(jc + 1u, (unsigned)ncols - 1u)], rkm = g.rkm[jc];
+    const bool edge_lane = (lane == 0 && jc >= 1u) || (lane == 63 && jc + 1u < (unsigned)ncols);
+    // first double of the 16-byte granule a lane asks for (rows are ld doubles long, ld a multiple of 16, so a
+    // granule clamped to ld - 2 stays inside its row; clamped granules hold columns no node reads)
+    const int gmax = g.ld - 2;
+    const unsigned gs = (unsigned)min(max(col0 - 2 + 2 * min(lane, 33), 0), gmax);  // stencil arrays, lanes 0..33
+    const unsigned gn = (unsigned)min(col0 + 2 * (lane & 31), gmax);               // node arrays, two per instruction
+    const bool s_lane = lane < 34, outer = (lane == 0 || lane == 33);
+
+    const double* sp[NS];
+    const double* cp[NC];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) sp[k] = f.sptr(k);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) cp[k] = f.cptr(k);
+
+    auto row_of = [&](int li) { return (size_t)min(max(li, 0), rmax) * g.ld; };
+    // everything row li needs that the wave does not hold yet: row li + 1 of the stencil arrays (and the outer
+    // granules of row li), row li of the node arrays
+    auto request = [&](int slot, int li) {
+        const size_t oc = row_of(li), on = row_of(li + 1);
+        const size_t os = outer ? oc : on;
+        double* base = &ring[wave][slot][0];
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+            if (s_lane) __builtin_amdgcn_global_load_lds((global_void_ptr)(sp[k] + os + gs), (lds_void_ptr)(base + 68 * k), 16, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NC; k += 2) {
+            const double* src = (lane < 32 || k + 1 >= NC) ? cp[k] : cp[k + 1 < NC ? k + 1 : k];
+            const bool on_duty = (lane < 32 || k + 1 < NC) && src != nullptr;
+            if (on_duty)
+                __builtin_amdgcn_global_load_lds((global_void_ptr)(src + oc + gn), (lds_void_ptr)(base + 68 * NS + 64 * k), 16, 0, 0);
+        }
+    };
+
+    double w[NS], c[NS], e[NS], edge[NS], cv[NC];
+    {
+        const size_t ow = row_of(ra - 1), oc = row_of(ra);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            w[k] = (sp[k] + ow)[jc];
+            c[k] = (sp[k] + oc)[jc];
+        }
+    }
+    // Row metrics of the row being computed, requested a row ahead like everything else and BEFORE the batch of
+    // that row: vector loads complete in order, so the wait for these never waits for the batch behind them.
+    double m_rh0 = g.rh[min(ra, rmax)], m_rh1 = g.rh[min(min(ra, rmax) + 1, rmax)], m_rhm = g.rhm[min(ra, rmax)];
+    request(0, ra);
+    for (int li = ra; li < rb; ++li) {
+        const int slot = (li - ra) & 1;
+        {
+            const double* base = &ring[wave][slot][0];
+            // The batch asked for a row ago has arrived once every vector memory operation of the wave has (they
+            // complete in order; the only younger ones are the stores of the row before).  The compiler does not
+            // connect the reads below with the loads that wrote LDS: the wait is spelled out.
+            // (the builtin, not an asm string: the compiler's own bookkeeping of outstanding loads sees it.  gfx9
+            // encoding: vmcnt 0, expcnt and lgkmcnt left alone)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                e[k] = base[68 * k + 2 + lane];
+                const double ev = base[68 * k + (lane == 0 ? 1 : 66)];
+                edge[k] = edge_lane ? ev : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < NC; ++k) cv[k] = cp[k] ? base[68 * NS + 64 * k + lane] : 0.0;
+            asm volatile("" ::: "memory");
+        }
+        const int l1 = min(li + 1, rmax);
+        const double n_rh1 = g.rh[min(l1 + 1, rmax)], n_rhm = g.rhm[l1];
+        asm volatile("" ::: "memory");
+        if (li + 1 < rb) request(slot ^ 1, li + 1);
+        St5 s[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            s[k].c = c[k];
+            s[k].e = e[k];
+            s[k].w = w[k];
+            s[k].n = lane_above_or(c[k], edge[k]);
+            s[k].s = lane_below_or(c[k], edge[k]);
+        }
+        const Geo ge{m_rh0, m_rh1, m_rhm, rks, rkn, rkm};  // = rh[lic], rh[min(lic + 1, rmax)], rhm[lic], lic = min(li, rmax)
+        if (col_ok) f.node(li, j, ge, s, cv);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            w[k] = c[k];
+            c[k] = e[k];
+        }
+        m_rh0 = m_rh1;
+        m_rh1 = n_rh1;
+        m_rhm = n_rhm;
+    }
+}
+
 }  // namespace tedd

@@ -333,6 +333,10 @@ struct PredictFn {
     // measured best at 16384^2: two waves per SIMD (the body needs ~180 registers) and 128-row segments
     static constexpr int kMarchOcc = 2, kMarchRows = 128;
     static constexpr bool kMarchAhead = false;
+    // Looks ahead in registers, at two waves per SIMD.  With the next row travelling into LDS instead (k_march_lds:
+    // 152 registers instead of 196, three waves per SIMD, 3 x 53 KB of LDS per compute unit) the launch takes the
+    // same 8.78 ms at 16384^2, alternated with this one inside one context: what bounds it is the memory system.
+    static constexpr bool kMarchLds = false;
     static constexpr int NS = 4, NC = 9;
     TEDD_HD const double* sptr(int k) const { return S.v[k]; }  // cp, T, cl, cd
     TEDD_HD const double* cptr(int k) const {
@@ -512,8 +516,9 @@ struct NewtonRhsFn {
 
     // ---- interface of the marching launcher (tedd_march.hpp): cl and cd systems with array-fed forcing
     static constexpr bool kMarches = (CASE == CASE_STREAM && VAR != VAR_T);
-    static constexpr int kMarchOcc = (VAR == VAR_CL) ? 4 : 3, kMarchRows = 64;
+    static constexpr int kMarchOcc = (VAR == VAR_CL) ? 4 : 3, kMarchRows = 32;
     static constexpr bool kMarchAhead = false;  // (measured best at 16384^2)
+    static constexpr bool kMarchLds = true;     // the next row travels into LDS while this one is computed (k_march_lds)
     static constexpr int NS = 4;                       // cp*, lagged T, lagged unknown, new T
     static constexpr int NC = (VAR == VAR_CL) ? 2 : 5;  // Y, forcing | + lagged cl, cs*, new cl
     TEDD_HD const double* sptr(int k) const {
