@@ -223,8 +223,10 @@ __device__ __forceinline__ bool cs_stop_after(const unsigned long long* gmax, co
                                               double rtol) {
     return __longlong_as_double((long long)gmax[k]) < rtol * __longlong_as_double((long long)gmin[k]);
 }
-template <int CASE, bool FLAT = false>
-__global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_REG> a, int r0, int r1, int ncols,
+// KREG: iterations whose record a thread keeps in registers (8 serves every count up to 8; the build for 5, the
+// default count, needs 12 registers fewer, which is one more wave per SIMD)
+template <int CASE, bool FLAT = false, int KREG = 8>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KREG <= 5 ? 5 : 4, 8))) k_cs_newton(const CorrectIn<CASE, REACT_REG> a, int r0, int r1, int ncols,
                                                   int tiles_x, int ntiles, double* cp_out, double* cs_out, int iters,
                                                   bool record, double rtol, int* out_keep, unsigned long long* gmax,
                                                   unsigned long long* gmin) {
@@ -259,7 +261,7 @@ __global__ void __launch_bounds__(256) k_cs_newton(const CorrectIn<CASE, REACT_R
         seen_mn = __atomic_load_n(gmin + tid, __ATOMIC_RELAXED);
     }
     // per-thread record of the first kCsReg iterations (the usual case: 5), reduced once at the end
-    constexpr int kCsReg = 8;
+    constexpr int kCsReg = KREG;
     const bool in_regs = (iters <= kCsReg);
     double rmx[kCsReg], rmn[kCsReg];
 #pragma unroll
@@ -439,6 +441,7 @@ struct HipBackend {
     // launcher's many small workgroups fill the GPU better), 0 never, 1 always
     int opt_march = -1;
     int opt_march_rows = 0;  // rows per segment (0: per functor, fewer on slabs with few rows)
+    int opt_cs_lean = 1;          // cs corrector of at most 5 iterations: the build with 5 records per thread, 5 waves per SIMD
     int opt_march_lds = -1;       // marching kernels without look-ahead in registers prefetch through LDS (-1: per functor)
     int opt_march_ahead = -1;     // marching kernels request the next row a row ahead (-1: per functor)
     int opt_strip_panel = 8;      // tile rows per panel of the strip launches' tile order (0: row-major)
@@ -1340,19 +1343,26 @@ struct HipBackend {
             if (iters > 4096) throw std::runtime_error("more than 4096 cs Newton iterations");
             // as many workgroups as the chip holds at once: each walks over an equal share of the tiles (a
             // grid larger than that runs its surplus as a second, thinner round)
-            static int per_cu = 0;
-            if (per_cu == 0) {
+            // (tiled launches of at most 5 iterations -- the default count -- use the build that keeps 5 records per
+            // thread and runs 5 waves per SIMD)
+            const bool lean = !flat && iters <= 5 && opt_cs_lean != 0;
+            static int per_cu[2] = {0, 0};
+            if (per_cu[lean] == 0) {
                 int n = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cs_newton<CASE, false>, kTileX * kTileY, lds) != hipSuccess || n < 1)
-                    n = 4;
-                per_cu = n;
+                const hipError_t e = lean ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cs_newton<CASE, false, 5>, kTileX * kTileY, lds)
+                                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cs_newton<CASE, false>, kTileX * kTileY, lds);
+                if (e != hipSuccess || n < 1) n = 4;
+                per_cu[lean] = n;
             }
-            nb = std::min(nb, per_cu * num_cus);
+            nb = std::min(nb, per_cu[lean] * num_cus);
             if (!skip_record) {
                 if (iters > 0 && cs_record_clean < iters)
                     hipLaunchKernelGGL(k_cs_init, dim3((iters + 255) / 256), dim3(256), 0, stream, gmax, gmin, iters);
                 if (flat)
                     hipLaunchKernelGGL((k_cs_newton<CASE, true>), dim3(nb), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols,
+                                       tx, nt, cp_out, cs_out, iters, true, rtol, d_keep, gmax, gmin);
+                else if (lean)
+                    hipLaunchKernelGGL((k_cs_newton<CASE, false, 5>), dim3(nb), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols,
                                        tx, nt, cp_out, cs_out, iters, true, rtol, d_keep, gmax, gmin);
                 else
                     hipLaunchKernelGGL((k_cs_newton<CASE, false>), dim3(nb), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols,
@@ -1372,6 +1382,9 @@ struct HipBackend {
             const int nb2 = (nt <= 4096) ? std::min(nb, std::max(32, nt / 16)) : nb;
             if (iters > 1 && flat)
                 hipLaunchKernelGGL((k_cs_newton<CASE, true>), dim3(nb2), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx,
+                                   nt, cp_out, cs_out, iters, false, rtol, d_keep, gmax, gmin);
+            else if (iters > 1 && lean)
+                hipLaunchKernelGGL((k_cs_newton<CASE, false, 5>), dim3(nb2), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx,
                                    nt, cp_out, cs_out, iters, false, rtol, d_keep, gmax, gmin);
             else if (iters > 1)
                 hipLaunchKernelGGL((k_cs_newton<CASE, false>), dim3(nb2), dim3(kTileX, kTileY), lds, stream, a, r0, r1, ncols, tx,
