@@ -350,16 +350,27 @@ TEDD_HD MmsColTabs<CASE> mms_col_tabs(const MmsTabs& t, int j) {
     for (int n = 0; n < MmsColTabs<CASE>::NM; ++n) c.ym[n] = (QUAD != 2) ? tab_ymom(t, MmsColTabs<CASE>::NBQ, n, j) : 0.0;
     return c;
 }
+// Row entries of a column walker: one address per wave.  On the device they are read through the constant
+// address space (the tables are written before the launch and never during it), which makes them scalar loads
+// whatever stores the kernel performs in between: a vector load of a uniform address would queue up behind, and
+// be waited for together with, everything else the wave has in flight.
+TEDD_HD double tab_row_entry(const double* p, size_t idx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ((const __attribute__((address_space(4))) double*)p)[idx];
+#else
+    return p[idx];
+#endif
+}
 template <int CASE>
-TEDD_HD double tab_x(const MmsColTabs<CASE>& t, int k, int li) { return t.bx[(size_t)k * t.nrows + li]; }
+TEDD_HD double tab_x(const MmsColTabs<CASE>& t, int k, int li) { return tab_row_entry(t.bx, (size_t)k * t.nrows + li); }
 template <int CASE>
 TEDD_HD double tab_y(const MmsColTabs<CASE>& t, int k, int) { return t.y[k]; }
 template <int CASE>
-TEDD_HD double tab_xq(const MmsColTabs<CASE>& t, int k, int a, int li) { return t.bxq[((size_t)k * 3 + a) * t.nrows + li]; }
+TEDD_HD double tab_xq(const MmsColTabs<CASE>& t, int k, int a, int li) { return tab_row_entry(t.bxq, ((size_t)k * 3 + a) * t.nrows + li); }
 template <int CASE>
 TEDD_HD double tab_yq(const MmsColTabs<CASE>& t, int k, int b, int) { return t.yq[k * 3 + b]; }
 template <int CASE>
-TEDD_HD double tab_xmom(const MmsColTabs<CASE>& t, int nbq, int n, int li) { return t.bxq[((size_t)nbq * 3 + n) * t.nrows + li]; }
+TEDD_HD double tab_xmom(const MmsColTabs<CASE>& t, int nbq, int n, int li) { return tab_row_entry(t.bxq, ((size_t)nbq * 3 + n) * t.nrows + li); }
 template <int CASE>
 TEDD_HD double tab_ymom(const MmsColTabs<CASE>& t, int, int n, int) { return t.ym[n]; }
 
