@@ -154,9 +154,10 @@ k_march(const F f, int r0, int r1, int ncols, int seg_rows, int tiles_x) {
 // row, hidden only by the other waves of the SIMD.  Here a wave owns two slots of LDS and asks for everything
 // row li+1 will need while it computes row li, with loads that write straight into LDS (16 bytes per lane, lane
 // l at byte 16 l of the destination: global_load_lds_dwordx4): of every stencil array the 64 doubles of its
-// columns in row li+2 -- lanes 1..32 -- and, as lanes 0 and 33, the two granules that hold columns -1 and 64 of
-// row li+1 (the row that will then be the centre: what lanes 0 and 63 need from outside the wave); of the arrays
-// read at the node alone, two per instruction, the 64 doubles of row li+1.  At the top of the next row the wave
+// columns in row li+2 and the two granules on either side of them (lanes 0..33: columns -2 .. 65; columns -1 and
+// 64 are what lanes 0 and 63 need from outside the wave once that row is the centre, one row later, so those two
+// values are carried in registers for a row); of the arrays read at the node alone, two per instruction, the 64
+// doubles of row li+1.  At the top of the next row the wave
 // waits for that one batch, reads it from LDS (consecutive lanes, consecutive doubles: no bank conflicts) and
 // asks for the next.  Registers as in k_march without look-ahead; LDS 2 x (68 NS + 64 NC) doubles per wave.
 // Same node bodies on the same values: bit-identical results.
@@ -193,7 +194,8 @@ k_march_lds(const F f, int r0, int r1, int ncols, int seg_rows, int tiles_x) {
     const int gmax = g.ld - 2;
     const unsigned gs = (unsigned)min(max(col0 - 2 + 2 * min(lane, 33), 0), gmax);  // stencil arrays, lanes 0..33
     const unsigned gn = (unsigned)min(col0 + 2 * (lane & 31), gmax);               // node arrays, two per instruction
-    const bool s_lane = lane < 34, outer = (lane == 0 || lane == 33);
+    const bool s_lane = lane < 34;
+    const unsigned je = (lane == 0) ? (jc >= 1u ? jc - 1u : 0u) : jc + 1u;  // (as k_march: the first row's outside value)
 
     const double* sp[NS];
     const double* cp[NC];
@@ -207,11 +209,10 @@ k_march_lds(const F f, int r0, int r1, int ncols, int seg_rows, int tiles_x) {
     // granules of row li), row li of the node arrays
     auto request = [&](int slot, int li) {
         const size_t oc = row_of(li), on = row_of(li + 1);
-        const size_t os = outer ? oc : on;
         double* base = &ring[wave][slot][0];
 #pragma unroll
         for (int k = 0; k < NS; ++k)
-            if (s_lane) __builtin_amdgcn_global_load_lds((global_void_ptr)(sp[k] + os + gs), (lds_void_ptr)(base + 68 * k), 16, 0, 0);
+            if (s_lane) __builtin_amdgcn_global_load_lds((global_void_ptr)(sp[k] + on + gs), (lds_void_ptr)(base + 68 * k), 16, 0, 0);
 #pragma unroll
         for (int k = 0; k < NC; k += 2) {
             const double* src = (lane < 32 || k + 1 >= NC) ? cp[k] : cp[k + 1 < NC ? k + 1 : k];
@@ -221,13 +222,14 @@ k_march_lds(const F f, int r0, int r1, int ncols, int seg_rows, int tiles_x) {
         }
     };
 
-    double w[NS], c[NS], e[NS], edge[NS], cv[NC];
+    double w[NS], c[NS], e[NS], edge[NS], edge_e[NS], cv[NC];
     {
         const size_t ow = row_of(ra - 1), oc = row_of(ra);
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             w[k] = (sp[k] + ow)[jc];
             c[k] = (sp[k] + oc)[jc];
+            edge[k] = edge_lane ? (sp[k] + oc)[je] : 0.0;
         }
     }
     // Row metrics of the row being computed, requested a row ahead like everything else and BEFORE the batch of
@@ -248,8 +250,8 @@ k_march_lds(const F f, int r0, int r1, int ncols, int seg_rows, int tiles_x) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 e[k] = base[68 * k + 2 + lane];
-                const double ev = base[68 * k + (lane == 0 ? 1 : 66)];
-                edge[k] = edge_lane ? ev : 0.0;
+                const double ev = base[68 * k + (lane == 0 ? 1 : 66)];  // (of the row that is the centre next)
+                edge_e[k] = edge_lane ? ev : 0.0;
             }
 #pragma unroll
             for (int k = 0; k < NC; ++k) cv[k] = cp[k] ? base[68 * NS + 64 * k + lane] : 0.0;
@@ -274,6 +276,7 @@ k_march_lds(const F f, int r0, int r1, int ncols, int seg_rows, int tiles_x) {
         for (int k = 0; k < NS; ++k) {
             w[k] = c[k];
             c[k] = e[k];
+            edge[k] = edge_e[k];
         }
         m_rh0 = m_rh1;
         m_rh1 = n_rh1;
