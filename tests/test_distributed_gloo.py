@@ -26,6 +26,14 @@ STRESS = [8.3144621, 1.60217662e-19, 0.11, 0.23, 0.37, 0.19, 2e-2, 3e-2, 0.4, 0.
           5e-2, 300.0]
 
 
+def _free_port():
+    """A TCP port nobody listens on right now (for the rendezvous of the ranks a test starts)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_partition_covers_all_rows():
     for n_rows in (9, 33, 257, 16385):
         for world in (1, 2, 3, 8):
@@ -121,7 +129,7 @@ def test_slab_run_equals_single_domain(world, kind, case, consts, options, tmp_p
     sweeps = [4, 3, 2]
     ghost = sum(sweeps) + 2 if kind == "pc" else 1
     ref_state, ref_norms = _single(case, N, M, nsteps, kind, consts, sweeps)
-    port = 29500 + (os.getpid() % 2000) + world
+    port = _free_port()
     mp.spawn(_worker, args=(world, port, case, N, M, nsteps, kind, consts, sweeps, ghost, str(tmp_path), options),
              nprocs=world, join=True)
     rows = 0
@@ -214,7 +222,7 @@ def test_cs_corrector_early_exit_is_decided_over_all_slabs(world, tmp_path):
     for use_hook in (True, False):
         out = tmp_path / f"hook{int(use_hook)}"
         out.mkdir()
-        port = 29500 + (os.getpid() % 2000) + 20 + world + 4 * int(use_hook)
+        port = _free_port()
         mp.spawn(_early_exit_worker, args=(world, port, N, M, nsteps, kw, 11, use_hook, str(out)), nprocs=world, join=True)
         seen[use_hook] = [np.load(out / f"exit{r}.npz") for r in range(world)]
     for z in seen[True]:
@@ -275,7 +283,7 @@ def test_sharded_sweep_reproduces_the_notebook(tmp_path):
     import json
     from test_twin_cabi_parity import build_twin
     build_twin()
-    port = 29500 + (os.getpid() % 2000) + 7
+    port = _free_port()
     mp.spawn(_sweep_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     out = json.loads((tmp_path / "sweep0.txt").read_text().strip().splitlines()[-1])
     assert (tmp_path / "sweep1.txt").read_text().strip() == ""

@@ -21,6 +21,14 @@ NB_A = [8.3144621, 1.60217662e-19, 1e-3, 1e-3, 1e-3, 1e-3, 1e-3, 1e-5, 1e-5, 1e-
 N, M, NSTEPS, SWEEPS = 300, 130, 3, [5, 3, 2]
 
 
+def _free_port():
+    """A TCP port nobody listens on right now (for the rendezvous of the ranks a test starts)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _run(ctx, stepper=None):
     ctx.set_state_exact(0.0)
     dt, t = (1.0 / N) ** 1.5, 0.0
@@ -68,7 +76,7 @@ def test_two_slabs_equal_single_slab(tmp_path, options):
                        mms_case=_ffi.MMS_EXPSIN)
     ref = _run(ctx)
     ctx.close()
-    port = 29700 + (os.getpid() % 1000)
+    port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path), options), nprocs=2, join=True)
     for r in range(2):
         z = np.load(tmp_path / f"rank{r}.npz")

@@ -109,7 +109,10 @@ dist.destroy_process_group()
 
 
 def test_rccl_paths_with_one_rank(tmp_path):
-    port = 29900 + (os.getpid() % 90)
+    import socket
+    with socket.socket() as sk:   # a port nobody listens on right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     script = tmp_path / "worker.py"
     script.write_text(f"ROOT = {ROOT!r}\nPORT = {port}\n" + WORKER)
     env = dict(os.environ)
