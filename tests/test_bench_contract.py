@@ -43,9 +43,11 @@ def test_committed_pmc_summary_feeds_the_traffic_figure():
     assert tr is not None and tr["source"].startswith("profiles/" + bench.PMC_PROFILE_TAG)
     algorithmic = 8.0 * 16385 * 16385 * 21
     assert algorithmic < tr["bytes_per_launch"] < 1.05 * algorithmic     # every array row is read once
-    for fam, arrays in (("rhs_cl", 7), ("rhs_cd", 10), ("forcing", 5), ("cs_newton", 8)):
+    # (the right-hand sides march with their next row travelling into LDS: the two 16-byte granules a wave asks for
+    # outside its own 64 columns are requests of their own, a few per cent of the launch's traffic)
+    for fam, arrays, slack in (("rhs_cl", 7, 1.08), ("rhs_cd", 10, 1.08), ("forcing", 5, 1.05), ("cs_newton", 8, 1.05)):
         got = bench.pmc_traffic(fam, cfg)["bytes_per_launch"]
-        assert 0.99 * arrays < got / (8.0 * 16385 * 16385) < 1.05 * arrays, fam
+        assert 0.99 * arrays < got / (8.0 * 16385 * 16385) < slack * arrays, fam
     assert bench.pmc_traffic("predict", dict(cfg, mesh_N=123)) is None
 
 
