@@ -330,8 +330,9 @@ struct PredictFn {
     // reads with its four neighbours, the arrays it reads at the node alone (a null pointer reads as 0),
     // and the node body on values the wave holds in registers
     static constexpr bool kMarches = (CASE == CASE_STREAM && FCASE == CASE_STREAM);
-    // measured best at 16384^2: two waves per SIMD (the body needs ~180 registers) and 128-row segments
-    static constexpr int kMarchOcc = 2, kMarchRows = 128;
+    // measured best at 16384^2: two waves per SIMD (the body needs ~180 registers) and 32-row segments (alternated
+    // inside one context: 8.6 ms with 32 rows, 8.65 with 24, 8.7 with 48, 8.8 with 16 or 128, 9.1 with 256)
+    static constexpr int kMarchOcc = 2, kMarchRows = 32;
     static constexpr bool kMarchAhead = false;
     // Looks ahead in registers, at two waves per SIMD.  With the next row travelling into LDS instead (k_march_lds:
     // 152 registers instead of 196, three waves per SIMD, 3 x 53 KB of LDS per compute unit) the launch takes the
