@@ -110,7 +110,7 @@ int tedd_set_mms_program(tedd_ctx* ctx, int32_t which, const uint32_t* code, int
  * record pass of the RegHCsTriple cs corrector on whole-mesh contexts (one launch fewer, bit-identical results);
  * "warm_start" (default 1): a Newton solve whose sweep count the library chooses starts its Jacobi iteration
  * from the increment of the step before instead of zero (same tolerance, fewer sweeps); "march" (default -1:
- * slabs of at least 2^25 nodes; 0 never, 1 always): the predictor and the right-hand sides of the cl and cd
+ * the right-hand sides on slabs above 4 M nodes, the predictor from 2^27 nodes; 0 never, 1 always): the predictor and the right-hand sides of the cl and cd
  * systems run in the marching launcher (a wavefront walks down 64 columns with the stencil rows in registers:
  * every array row is read once) instead of one thread per node -- bit-identical results; "march_rows",
  * "march_occ": rows per segment and waves per SIMD of that launcher (0: the kernel's own choice); "march_lds"

@@ -437,7 +437,7 @@ struct Marches<F, std::enable_if_t<F::kMarches>> : std::true_type {};
 
 struct HipBackend {
     static constexpr bool kHasStripSolve = true;
-    // marching launcher for the stencil functors: -1 on slabs of at least 2^25 nodes (below, the plain
+    // marching launcher for the stencil functors: -1 from the slab size each functor names (kMarchMinNodes; below, the plain
     // launcher's many small workgroups fill the GPU better), 0 never, 1 always
     int opt_march = -1;
     int opt_march_rows = 0;  // rows per segment (0: per functor, fewer on slabs with few rows)
@@ -716,7 +716,7 @@ struct HipBackend {
         bool marching = false;
         if constexpr (Marches<F>::value) {
             const long long n = (long long)(r1 - r0) * ncols;
-            marching = opt_march > 0 || (opt_march < 0 && n >= (1LL << 25));
+            marching = opt_march > 0 || (opt_march < 0 && n >= F::kMarchMinNodes);
         }
         if (marching || r1 == r0) {
             step_prologue(a);
@@ -942,7 +942,7 @@ struct HipBackend {
         Scope sc(this, fam);
         if constexpr (Marches<F>::value) {
             const long long n = (long long)(r1 - r0) * ncols;
-            if (opt_march > 0 || (opt_march < 0 && n >= (1LL << 25))) {
+            if (opt_march > 0 || (opt_march < 0 && n >= F::kMarchMinNodes)) {
                 const int tiles_x = (ncols + 64 * kMarchWaves - 1) / (64 * kMarchWaves);
                 int seg = opt_march_rows > 0 ? opt_march_rows : F::kMarchRows;
                 // enough workgroups for every compute unit to see many: shorter segments on slabs with few rows

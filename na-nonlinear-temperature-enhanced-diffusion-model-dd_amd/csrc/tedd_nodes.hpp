@@ -333,6 +333,9 @@ struct PredictFn {
     // measured best at 16384^2: two waves per SIMD (the body needs ~180 registers) and 32-row segments (alternated
     // inside one context: 8.6 ms with 32 rows, 8.65 with 24, 8.7 with 48, 8.8 with 16 or 128, 9.1 with 256)
     static constexpr int kMarchOcc = 2, kMarchRows = 32;
+    // slabs from which the launch marches by itself: with one thread per node it is the faster one up to 8192^2
+    // (2.25 against 2.30 ms there, 0.55 against 0.59 at 4096^2; 9.4 against 8.6 at 16384^2)
+    static constexpr long long kMarchMinNodes = 1LL << 27;
     static constexpr bool kMarchAhead = false;
     // Looks ahead in registers, at two waves per SIMD.  With the next row travelling into LDS instead (k_march_lds:
     // 152 registers instead of 196, three waves per SIMD, 3 x 53 KB of LDS per compute unit) the launch takes the
@@ -519,6 +522,9 @@ struct NewtonRhsFn {
     static constexpr bool kMarches = (CASE == CASE_STREAM && VAR != VAR_T);
     static constexpr int kMarchOcc = (VAR == VAR_CL) ? 4 : 3, kMarchRows = 32;
     static constexpr bool kMarchAhead = false;  // (measured best at 16384^2)
+    // marches wherever it is a launch of its own (slabs above the 4 M nodes up to which the solves evaluate their
+    // right-hand sides themselves): rhs_cl 0.14 -> 0.11 ms at 3072^2, 0.23 -> 0.20 at 4096^2, 0.92 -> 0.78 at 8192^2
+    static constexpr long long kMarchMinNodes = 1LL << 22;
     static constexpr bool kMarchLds = true;     // the next row travels into LDS while this one is computed (k_march_lds)
     static constexpr int NS = 4;                       // cp*, lagged T, lagged unknown, new T
     static constexpr int NC = (VAR == VAR_CL) ? 2 : 5;  // Y, forcing | + lagged cl, cs*, new cl
