@@ -1179,7 +1179,7 @@ struct HipBackend {
     }
     // one launch of the register-resident Newton solve chain (tedd_strip.hpp)
     // shape: SHAPE_LARGE / SHAPE_SMALL / SHAPE_MID, or -1 = by mesh size and system: small tiles when
-    // the large ones would leave compute units without work (fewer than 2 tiles per unit); otherwise
+    // the large ones would leave most compute units without work (fewer than half a tile per unit); otherwise
     // large tiles for T and 48-row tiles for cl and cd (tedd_strip.hpp, StripShape).  A shape whose
     // tile the depth H does not fit falls back to the large one.
     // tile shape of a strip launch of depth H over rows [r0, r1): the caller's choice, or by mesh size and system
@@ -1192,7 +1192,10 @@ struct HipBackend {
         };
         auto fits = [&](int sh) { return strip_tile_rows(sh) - 2 * H >= (sh == SHAPE_TINY ? 6 : 8); };
         if (shape < 0) {
-            if (fits(SHAPE_SMALL) && n_tiles(SHAPE_LARGE) < 2LL * num_cus) {
+            // (half a tile per compute unit is where the small tiles stop paying: alternated inside one context,
+            // per step with small tiles / with the shapes of large meshes: 512^2 0.11 / 0.11 ms, 640^2 0.16 / 0.14,
+            // 768^2 0.20 / 0.17, 1024^2 0.31 / 0.24 -- the T chain alone 0.11 / 0.04 there; 256^2 0.05 / 0.07)
+            if (fits(SHAPE_SMALL) && n_tiles(SHAPE_LARGE) < num_cus / 2) {
                 // too few tiles to fill the chip: the latency of one tile is the run time
                 shape = SHAPE_SMALL;
                 // ... and compute units to spare: two rows per thread (cl, cd)
@@ -1213,7 +1216,7 @@ struct HipBackend {
     }
     // one launch of the register-resident Newton solve chain (tedd_strip.hpp)
     // shape: SHAPE_LARGE / SHAPE_SMALL / SHAPE_MID, or -1 = by mesh size and system: small tiles when
-    // the large ones would leave compute units without work (fewer than 2 tiles per unit); otherwise
+    // the large ones would leave most compute units without work (fewer than half a tile per unit); otherwise
     // large tiles for T and 48-row tiles for cl and cd (tedd_strip.hpp, StripShape).  A shape whose
     // tile the depth H does not fit falls back to the large one.
     template <int VAR, int REACT, bool LAST>
