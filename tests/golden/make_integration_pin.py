@@ -13,9 +13,17 @@ field, forcing terms and StateVars -- and as integrator_cls
   (b) the binding over the host-compiled library (tests/cpu_twin), forcing streamed from the reference's field,
   (c) the binding with the library's own closed-form ExpSin forcing.
 The NumericalErrorSummary of (b) and (c) must match (a) to 1e-9 relative; one step from the initial state must
-match to 1e-11 absolute.  The numbers of (a), and what (b) and (c) gave here, are written to
-golden_integration_pin.json: tests/test_reference_stub.py repeats (b) and (c) with this package's mirror of the
-reference's classes and checks them against the reference's numbers, wherever the test suite runs.
+match to 1e-11 absolute.  Two more scenarios of the reference's own tests run through the binding:
+  - the residual check of tests/test_newton_residuals.py:56-124 (N = 8, dt = 1e-4, 5 Newton steps, 1 and 20 time
+    steps, ||last_residual[v]||_H < 1e-9 for v = T, cl, cd, the norms taken with the reference's Grid.norm_H), for
+    the reference's integrator and for the binding; the reference's norms are stored;
+  - the residual ARRAYS after one Newton step (where they are not zero): binding against reference to 1e-12;
+  - a model constant changed in place on the integrator between two steps (integrator._model.Kd, as
+    tests/test_time_integrator_hcs_triple.py:377-387 does): the streamed binding must follow the reference's
+    integrator to 1e-11 absolute through the change and back; the closed-form binding must refuse.
+The numbers of (a), and what (b) and (c) gave here, are written to golden_integration_pin.json:
+tests/test_reference_stub.py repeats (b) and (c) with this package's mirror of the reference's classes and checks
+them against the reference's numbers, wherever the test suite runs.
 """
 import json
 import os
@@ -36,13 +44,13 @@ TWIN = os.path.join(ROOT, "tests", "cpu_twin", "libtedd_twin.so")
 N, ETA, TF = 16, 50.0, 0.01
 
 
-def trial(integrator_cls):
+def trial(integrator_cls, case_cls=None):
     with open(os.path.join(HERE, "model_sets.json")) as fh:
         consts = json.load(fh)["nb_a"]
     model = p1.DefaultModel02(p1.ModelConsts(**consts))
     grid = p1.make_uniform_grid(N=N, M=N)
     common = {"regularization_factor": ETA}
-    return mtu.MMSTrial(grid=grid, model=model, mms_case_cls=p1mc.MMSCaseExpSin,
+    return mtu.MMSTrial(grid=grid, model=model, mms_case_cls=case_cls or p1mc.MMSCaseExpSin,
                         field_cls=p1.SemiDiscreteField_RegHCsTriple, forcing_terms_cls=p1.ForcingTerms_RegHCsTriple,
                         integrator_cls=integrator_cls, integrator_params=dict(common),
                         forcing_terms_params=common, field_params=common)
@@ -57,6 +65,48 @@ def summary(tr):
 def one_step(tr):
     out = tr.integrator.step(tr.initial_state, t0=0.0, dt=(1.0 / N) ** 1.5)
     return [np.array(getattr(out, v)) for v in ("cp", "T", "cl", "cd", "cs")]
+
+
+RES_N, RES_DT, RES_ATOL = 8, 1e-4, 1e-9       # tests/test_newton_residuals.py:60-66
+
+
+def residual_norms(integrator_cls, num_time_steps, num_newton_steps=5, arrays=False):
+    """tests/test_newton_residuals.py:68-124 with the given integrator class (arrays: the residual arrays of the
+    last step instead of the worst norms)."""
+    with open(os.path.join(HERE, "model_sets.json")) as fh:
+        model = p1.DefaultModel02(p1.ModelConsts(**json.load(fh)["nb_a"]))
+    grid = p1.make_uniform_grid(N=RES_N, M=RES_N)
+    common = {"regularization_factor": ETA}
+    tr = mtu.MMSTrial(grid=grid, model=model, mms_case_cls=p1mc.MMSCaseExpSin,
+                      field_cls=p1.SemiDiscreteField_RegHCsTriple, forcing_terms_cls=p1.ForcingTerms_RegHCsTriple,
+                      integrator_cls=integrator_cls, integrator_params=dict(common, num_newton_steps=num_newton_steps),
+                      forcing_terms_params=common, field_params=common)
+    state, t, worst = tr.initial_state, 0.0, {"T": 0.0, "cl": 0.0, "cd": 0.0}
+    for _ in range(num_time_steps):
+        state = tr.integrator.step(at_t0=state, t0=t, dt=RES_DT)
+        t += RES_DT
+        for v in worst:
+            worst[v] = max(worst[v], float(grid.norm_H(tr.integrator.last_residual[v])))
+    if arrays:
+        return {v: np.array(tr.integrator.last_residual[v]) for v in worst}
+    return worst
+
+
+def mutated_model_states(integrator_cls):
+    """Three steps; Kd is multiplied by 50 on the integrator's own model object for the second one only.
+    (MMSCasePol: its exact solution does not depend on the model constants, so forcing arrays evaluated for the
+    constants of the moment are the same thing in the reference and in this package's mirror of its classes.)"""
+    tr = trial(integrator_cls, p1mc.MMSCasePol)
+    dt = (1.0 / N) ** 1.5
+    state, out = tr.initial_state, []
+    for k in range(3):
+        kd = tr.integrator._model.Kd
+        if k == 1:
+            tr.integrator._model.Kd = 50.0 * kd
+        state = tr.integrator.step(state, t0=k * dt, dt=dt)
+        tr.integrator._model.Kd = kd
+        out.append([np.array(getattr(state, v)) for v in ("cp", "T", "cl", "cd", "cs")])
+    return out
 
 
 def main():
@@ -82,6 +132,47 @@ def main():
         assert dev < 1e-11, (name, dev)
         res[name]["one_step_max_abs_deviation"] = dev
     res["one_step_state_checksums"] = [float(np.abs(a).sum()) for a in steps["reference"]]
+    res["newton_residuals"] = {"N": RES_N, "dt": RES_DT, "num_newton_steps": 5, "atol": RES_ATOL}
+    for name in ("reference", "binding_streamed", "binding_closed_form"):
+        for nsteps in (1, 20):
+            worst = residual_norms(kinds[name], nsteps)
+            print(name, "residual norms after", nsteps, "steps:", worst, flush=True)
+            assert max(worst.values()) < RES_ATOL, (name, nsteps, worst)
+            res["newton_residuals"].setdefault(name, {})[str(nsteps)] = worst
+    # (five Newton steps drive the interior residuals to exactly zero; after ONE they are not, and the arrays
+    # themselves are compared: boundary entries included, which hold the raw forcing values)
+    one = {name: residual_norms(kinds[name], 2, num_newton_steps=1, arrays=True) for name in kinds}
+    res["newton_residuals"]["one_newton_step_max_abs"] = {v: float(np.abs(a).max()) for v, a in one["reference"].items()}
+    res["newton_residuals"]["one_newton_step_interior_max_abs"] = {v: float(np.abs(a[1:-1, 1:-1]).max())
+                                                                  for v, a in one["reference"].items()}
+    res["newton_residuals"]["one_newton_step_checksums"] = {v: float(np.abs(a).sum()) for v, a in one["reference"].items()}
+    for name in ("binding_streamed", "binding_closed_form"):
+        dev = max(float(np.abs(one[name][v] - one["reference"][v]).max()) for v in ("T", "cl", "cd"))
+        print(name, "residual arrays after one Newton step: max deviation from the reference", dev, flush=True)
+        assert dev < 1e-12, (name, dev)
+        res["newton_residuals"][name + "_one_newton_step_max_abs_deviation"] = dev
+    ref_states = mutated_model_states(kinds["reference"])
+    res["mutated_Kd"] = {"factor": 50.0, "step": 1,
+                         "state_checksums": [[float(np.abs(a).sum()) for a in st] for st in ref_states]}
+    res["mutated_Kd"]["case"] = "MMSCasePol"
+    got = mutated_model_states(kinds["binding_streamed"])
+    dev = max(float(np.abs(a - b).max()) for g, r in zip(got, ref_states) for a, b in zip(g, r))
+    print("binding_streamed, mutated Kd: max deviation from the reference over three steps", dev, flush=True)
+    assert dev < 1e-11, dev
+    res["mutated_Kd"]["binding_streamed_max_abs_deviation"] = dev
+    # (with the library's own closed-form forcing a constant changed in place cannot be followed: the reference's
+    # lambdified exact solution keeps the constants it was built with, the library's case would not -- refused)
+    try:
+        mutated_model_states(kinds["binding_closed_form"])
+        raise AssertionError("closed-form binding accepted a model changed in place")
+    except NotImplementedError:
+        pass
+    # (the change must be visible at all: the second step of an unchanged model differs)
+    plain = trial(kinds["reference"], p1mc.MMSCasePol)
+    s1 = plain.integrator.step(plain.initial_state, t0=0.0, dt=(1.0 / N) ** 1.5)
+    s2 = plain.integrator.step(s1, t0=(1.0 / N) ** 1.5, dt=(1.0 / N) ** 1.5)
+    res["mutated_Kd"]["effect_on_cs"] = float(np.abs(np.array(s2.cs) - ref_states[1][4]).max())
+    assert res["mutated_Kd"]["effect_on_cs"] > 1e-9
     with open(os.path.join(HERE, "golden_integration_pin.json"), "w") as fh:
         json.dump(res, fh, indent=1)
     print("golden_integration_pin.json written")

@@ -28,3 +28,15 @@ def test_binding_reproduces_the_reference_trial_on_the_gpu(mms_case):
     out = tr.integrator.step(tr.initial_state, t0=0.0, dt=(1.0 / trs.PIN["N"]) ** 1.5)
     sums = [float(np.abs(getattr(out, v)).sum()) for v in ("cp", "T", "cl", "cd", "cs")]
     np.testing.assert_allclose(sums, trs.PIN["one_step_state_checksums"], rtol=1e-13)
+
+
+def test_last_residual_side_channel_on_the_gpu():
+    trs.check_last_residual(_ffi.DEFAULT_LIBRARY)
+
+
+def test_model_constants_are_read_at_every_step_on_the_gpu():
+    trs.check_model_changed_in_place(_ffi.DEFAULT_LIBRARY)
+
+
+def test_unconverged_solves_do_not_pass_silently_on_the_gpu():
+    trs.check_unconverged_solves_do_not_pass_silently(_ffi.DEFAULT_LIBRARY)
