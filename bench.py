@@ -130,15 +130,13 @@ def consts_vec(d):
     return [float(d[k]) for k in _ffi.CONST_NAMES]
 
 
-def pick_sweeps(N, dt, jacobi_tol):
-    """Sweep counts the library would pick (same contraction bound), needed up-front to size the ghost zone."""
-    q_metric = 4.0 * N * N
-    out = []
-    for D in (NB_A["DT"], NB_A["Dl_max"], NB_A["Dd_max"]):
-        q = dt * D * q_metric
-        rho = q / (2.0 + q)
-        out.append(max(2, int(np.ceil(np.log(jacobi_tol) / np.log(rho)) + 1)))
-    return out
+def pick_sweeps(N, dt, jacobi_tol, x=None, y=None, consts=None):
+    """Sweep counts the library would pick from a zero iterate (same contraction bound), needed up-front to size
+    the ghost zone.  Default: the uniform N x N mesh with the notebook constants."""
+    from tedd.distributed import a_priori_sweeps
+    u = np.linspace(0.0, 1.0, N + 1)
+    return a_priori_sweeps(u if x is None else x, u if y is None else y,
+                           consts_vec(NB_A) if consts is None else consts, dt, jacobi_tol)
 
 
 def study_mesh_run(N=256, steps=400, warmup=20):
@@ -360,7 +358,7 @@ def main():
     import torch
     import torch.distributed as dist
     from tedd import _ffi
-    from tedd.distributed import SlabStepper, partition_rows
+    from tedd.distributed import SlabStepper, ghost_rows_needed, partition_rows
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -387,11 +385,11 @@ def main():
     weak = args.scaling == "weak"
     rows_global = (N * world if weak else N) + 1     # weak: the domain grows along x with the ranks, same cell size
     dt = (1.0 / N) ** 1.5
-    sweeps_cap = pick_sweeps(N, dt, args.jacobi_tol)  # a-priori counts: size the ghost zone; the library's
-    ghost = sum(sweeps_cap) + 3                      # stopping rule never asks for more unless it reports it
-    slab = partition_rows(rows_global, world, rank, ghost)
     x = np.linspace(0.0, float(world) if weak else 1.0, rows_global)
     y = np.linspace(0.0, 1.0, N + 1)
+    sweeps_cap = pick_sweeps(N, dt, args.jacobi_tol, x=x, y=y)   # a-priori counts: they size the ghost zone
+    ghost = ghost_rows_needed(sweeps_cap, library_chosen=not args.fixed_sweeps)
+    slab = partition_rows(rows_global, world, rank, ghost)
     ctx = _ffi.Context(x, y, consts_vec(NB_A), model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
                        mms_case=_ffi.MMS_EXPSIN, row_lo=slab.row_lo, row_hi=slab.row_hi, ghost=slab.ghost,
                        device=local_rank if on_gpu else -1)

@@ -142,6 +142,13 @@ int tedd_sync(tedd_ctx* ctx);
 int32_t tedd_local_rows(const tedd_ctx* ctx);
 int32_t tedd_row_offset(const tedd_ctx* ctx); /* global index of local row 0 */
 int32_t tedd_pitch(const tedd_ctx* ctx);      /* device row pitch in doubles (>= M+1) */
+/* How the context's field buffers were placed in device memory, as text (no counterpart in the reference, whose
+ * arrays are NumPy's).  A context whose ~32 field buffers take 8 GiB or more carves them from ONE allocation, two
+ * buffer sizes apart while that fits into half of the free device memory (the gaps stay unused), packed back to
+ * back otherwise: launches that stream many arrays at once run up to 8 % slower with the buffers in consecutive
+ * separate allocations.  TEDD_FIELD_GAP_MB in the environment sets the gap (MiB; 0 packed, -1 separate
+ * allocations).  The string names the layout chosen, or why the buffers were allocated one by one. */
+const char* tedd_placement(const tedd_ctx* ctx);
 
 /* State (cp, T, cl, cd, cs): replaces StateVars' five arrays (src/prob1base.py:1959-2028). */
 int tedd_set_state(tedd_ctx* ctx, const double* cp, const double* T, const double* cl, const double* cd,
@@ -275,6 +282,15 @@ int tedd_check_converged(tedd_ctx* ctx);
  * fn = NULL removes the hook. */
 typedef int (*tedd_reduce_fn)(void* user, double* dev_max, double* dev_min, int32_t n);
 int tedd_set_reduce_hook(tedd_ctx* ctx, tedd_reduce_fn fn, void* user);
+
+/* The convergence record of the Newton solves of the step in flight: *n non-negative doubles in the context's
+ * device memory, each a maximum over the context's rows (last update, increment, first update of a warm-started
+ * solve, size of the unknown, per system).  No counterpart in the reference (one process, direct solves).  The
+ * library chooses the sweep counts and the warm start of later steps from these records; on a decomposed mesh the
+ * driver replaces every entry by its maximum over all slabs after each step (one all-reduce with MAX of *n doubles,
+ * ordered on the context's stream after tedd_step_pc), so that every slab takes the decisions a single context
+ * holding the whole mesh would take. */
+int tedd_record_device_ptr(tedd_ctx* ctx, void** ptr, int32_t* n);
 
 /* Per-kernel device timing with HIP events on the context's stream.  enable != 0 starts
  * recording (and clears the totals).  tedd_profile_get returns, for up to `cap` kernel families,

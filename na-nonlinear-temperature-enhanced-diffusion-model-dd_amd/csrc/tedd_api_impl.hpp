@@ -120,6 +120,7 @@ int tedd_sync(tedd_ctx* ctx) {
 int32_t tedd_local_rows(const tedd_ctx* ctx) { return ctx && ctx->impl ? ctx->impl->nrows : -1; }
 int32_t tedd_row_offset(const tedd_ctx* ctx) { return ctx && ctx->impl ? ctx->impl->i0 : -1; }
 int32_t tedd_pitch(const tedd_ctx* ctx) { return ctx && ctx->impl ? ctx->impl->ld : -1; }
+const char* tedd_placement(const tedd_ctx* ctx) { return ctx && ctx->impl ? ctx->impl->placement() : ""; }
 
 int tedd_set_state(tedd_ctx* ctx, const double* cp, const double* T, const double* cl, const double* cd, const double* cs) {
     return guarded(ctx, [&](auto& C) {
@@ -140,6 +141,13 @@ int tedd_state_device_ptrs(tedd_ctx* ctx, void* ptrs[5]) {
         if (!ptrs) throw tedd::InvalidError("ptrs is null");
         C.require_state();
         for (int v = 0; v < 5; ++v) ptrs[v] = C.cur[v];
+    });
+}
+int tedd_record_device_ptr(tedd_ctx* ctx, void** ptr, int32_t* n) {
+    return guarded(ctx, [&](auto& C) {
+        if (!ptr || !n) throw tedd::InvalidError("null output pointer");
+        *ptr = C.d_red;
+        *n = 16;
     });
 }
 int tedd_prefetch_forcing(tedd_ctx* ctx, double t, double keep_t) {

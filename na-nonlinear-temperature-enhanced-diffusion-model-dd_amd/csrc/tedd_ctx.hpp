@@ -73,6 +73,11 @@ public:
     // intermediate unknowns are acquired from / released to the free list.
     enum Slot : int { Y0 = 0, RHS = 3, DA, DB, FCPA, FCPB, SF00 /*5*/, SF10 = 13 /*5*/, EX0 = 18 /*5*/, NSLOT = 23 };
     double* slot[NSLOT] = {nullptr};
+    static constexpr int kArenaSlots = 32;  // field buffers a predictor-corrector context holds at its peak
+    const char* placement() const {
+        if constexpr (Backend::kHasArena) return be.placement();
+        return "host memory";
+    }
     std::vector<double*> all_bufs, free_bufs;
     std::vector<double*> retained;  // kept alive after a step for tedd_get_residuals
     double* cur[5];
@@ -106,6 +111,13 @@ public:
     double* prev[3] = {nullptr, nullptr, nullptr};
     double prev_dt = 0.0;
     int opt_warm = 1;             // start the Jacobi iteration from the increment of the step before
+    // Floor of the stopping rule of the Newton solves, relative to the size of the unknown: a last update below
+    // opt_floor x max|u| counts as converged whatever the increment is (2^-62: 2^-10 of an ulp of the unknown; the
+    // verdict allows ten times that, 1 % of an ulp).  It comes into play only where tol x increment is smaller
+    // still, i.e. where a time step moves the unknown by less than 2e-6 of its size (jacobi_tol = 1e-13): the
+    // 16384^2 mesh with dt = h^1.5 (T moves by 9e-9 per step: tol x increment = 1e-21), not the study meshes up
+    // to 256^2.  Known only to warm-started solves, whose first sweep records max|u|.
+    double opt_floor = 0x1p-62;
     // a warm start reads two more arrays than a start from zero: where the record says it would not save
     // three sweeps or a launch, that system starts from zero until this sequence number (then it is tried again)
     long long cold_until[3] = {0, 0, 0};
@@ -210,10 +222,10 @@ public:
         // (a constructor that throws runs no destructor: what was allocated so far is released here)
         try {
             be.init(c.device);
-            if constexpr (Backend::kHasPrime) {
-                // large slabs (their ~32 field buffers take 8 GiB or more): see HipBackend::prime_memory
+            if constexpr (Backend::kHasArena) {
+                // large slabs (their ~32 field buffers take 8 GiB or more): see HipBackend::arena_setup
                 const size_t pool = 32 * field_elems() * sizeof(double);
-                if (pool >= ((size_t)8 << 30)) be.prime_memory(pool);
+                if (pool >= ((size_t)8 << 30)) be.arena_setup(field_elems() * sizeof(double), kArenaSlots);
             }
             set_model(c.consts, c.model_kind, c.eta, c.mms_params);
             build_geometry();
@@ -232,8 +244,9 @@ public:
     }
     ~Ctx() { release_all(); }
     void release_all() noexcept {
-        for (double* p : all_bufs) be.free(p);
-        for (double*& p : slot) be.free(p);
+        for (double* p : all_bufs) be.field_free(p);
+        for (double*& p : slot) be.field_free(p);
+        if constexpr (Backend::kHasArena) be.arena_release();
         be.free(d_geo_rows);
         be.free(d_geo_cols);
         be.free(d_bx);
@@ -518,7 +531,7 @@ public:
     // ------------------------------------------------------------------ buffers
     size_t field_elems() const { return (size_t)nrows * ld; }
     double* new_field() {
-        double* p = (double*)be.alloc(field_elems() * sizeof(double));
+        double* p = (double*)be.field_alloc(field_elems() * sizeof(double));
         be.memset0(p, field_elems() * sizeof(double));
         return p;
     }
@@ -932,7 +945,7 @@ public:
 
     // The record the prologue of step `seq + 1` published for step `seq`: waits (bounded) until it is there.
     // Returns false if the record cannot be had (never published, or overwritten).
-    bool lagged_record(long long seq, double* upd, double* inc, double* first) {
+    bool lagged_record(long long seq, double* upd, double* inc, double* first, double* umax) {
         if (seq < chain_start || seq < 0 || seq + kRing <= next_seq || seq + 1 >= next_seq) return false;
         const StepMeta& ms = meta[seq % kRing];
         if (ms.seq != seq || !(ms.warm[0] || ms.warm[1] || ms.warm[2])) return false;  // (never published)
@@ -946,6 +959,7 @@ public:
             upd[v] = slot[1 + v];
             inc[v] = slot[4 + v];
             first[v] = slot[7 + v];
+            umax[v] = slot[10 + v];
         }
         return slot[0] == want;
     }
@@ -962,10 +976,9 @@ public:
     // three sweeps or a launch of the chain; otherwise the system goes back to zero iterates for a while.
     void choose_sweeps(StepParams& p, const int32_t* sweeps_in, double jtol, int jmax, StepMeta& mt) {
         const double dcoef[3] = {model.DT, model.Dl_max, model.Dd_max};
-        const bool partial = (gl > 0 || gr > 0);
         const bool can_warm = opt_warm && !persist_step && p.num_pc > 0 && p.num_newton > 0 && prev_dt > 0.0 &&
                               next_seq > chain_start;
-        double upd[3], inc[3], first[3];
+        double upd[3], inc[3], first[3], umax[3];
         bool have_rec = false;
         bool asked = false;
         p.gscale = can_warm ? p.dt / prev_dt : 0.0;
@@ -987,9 +1000,13 @@ public:
             mt.tol[v] = jtol;
             if (can_warm && prev[v] && next_seq >= cold_until[v]) {
                 warm = true;
-                s = std::min(cold + (partial ? 0 : 1), jmax);  // until a record says how good the start is
+                // until a record says how good the start is: the cold count, all of it performed on the warm
+                // iterate (one sweep more than a cold chain runs after b = delta^1: one more ghost row per system
+                // on a slab, which is the "+ 3" of the ghost rule for library-chosen sweeps).  The same on a slab
+                // and on the whole mesh, so that a decomposed run repeats the single-domain iteration.
+                s = std::min(cold, jmax);
                 if (!asked) {
-                    have_rec = lagged_record(next_seq - kLag, upd, inc, first);
+                    have_rec = lagged_record(next_seq - kLag, upd, inc, first, umax);
                     asked = true;
                 }
                 const StepMeta& m2 = meta[(next_seq - kLag + 2 * kRing) % kRing];
@@ -1004,10 +1021,13 @@ public:
                     // sweeps after the first so that the last update is below tol / 4 (the start of this
                     // step is judged by that of an earlier one: the factor covers the difference)
                     const double r0 = 4.0 * first[v] / inc[v];
-                    if (r0 <= jtol || rho <= 0.0) {
+                    // (an update below opt_floor x max|u| needs no further sweep: StepRecordArgs::floor)
+                    double tol_eff = jtol;
+                    if (umax[v] == umax[v] && opt_floor * umax[v] > jtol * inc[v]) tol_eff = opt_floor * umax[v] / inc[v];
+                    if (r0 <= tol_eff || rho <= 0.0) {
                         s = 2;
                     } else if (rho < 1.0) {
-                        const double want = 1.0 + std::max(std::ceil(std::log(jtol / r0) / std::log(rho)), 0.0);
+                        const double want = 1.0 + std::max(std::ceil(std::log(tol_eff / r0) / std::log(rho)), 0.0);
                         if (want < (double)s) s = (int)want;
                     }
                     if (s < 2) s = 2;
@@ -1064,6 +1084,7 @@ public:
             ra.ring_slot = (have_before && any_warm) ? d_ring + 16 * ((next_seq - 1) % kRing) : nullptr;
             ra.seq = (double)(next_seq - 1);
             for (int v = 0; v < 3; ++v) ra.tol[v] = have_before ? mb.tol[v] : 0.0;
+            ra.floor = opt_floor;
             ra.clear = 1;
             ra.cs_iters = (react == REACT_REG) ? cs_iters : 0;
             // (carried out by the predictor launch where that is a plain node launch, else by a launch of its own)
@@ -1151,6 +1172,7 @@ public:
         ra.seq = 0.0;
         const StepMeta& mb = meta[(next_seq - 1 + kRing) % kRing];
         for (int v = 0; v < 3; ++v) ra.tol[v] = mb.tol[v];
+        ra.floor = opt_floor;
         ra.fold = 1;
         ra.clear = 0;
         ra.cs_iters = 0;
@@ -1838,6 +1860,9 @@ public:
         } else if (name == "warm_start") {
             opt_warm = value != 0.0;
             if (!opt_warm) drop_prev();
+        } else if (name == "jacobi_floor") {
+            if (!(value >= 0.0) || value > 1.0) throw InvalidError("jacobi_floor must be in [0, 1]");
+            opt_floor = value;
         }
         else
             throw InvalidError("unknown option: " + name);

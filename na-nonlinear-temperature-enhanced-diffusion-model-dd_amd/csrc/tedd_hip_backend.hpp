@@ -179,6 +179,7 @@ __device__ __forceinline__ void step_prologue_body(const StepRecordArgs& a, unsi
             slot[1 + v] = rec[2 * v];
             slot[4 + v] = rec[2 * v + 1];
             slot[7 + v] = rec[8 + 2 * v];
+            slot[10 + v] = rec[9 + 2 * v];
         }
         __threadfence_system();
         *(volatile double*)slot = a.seq;
@@ -657,33 +658,76 @@ struct HipBackend {
         }
         return ptr[dev];
     }
-    // Device memory that has been handed out, written and returned once before serves the streaming launches of
-    // a large slab faster than the memory the first process on a freshly started machine is given: on an MI355X
-    // the predictor of a 16384^2 mesh takes 9.2 ms per launch in such a first process, for the whole life of its
-    // context, and 8.3-8.8 ms in every later process, or in the first one after 100 GiB were allocated, zeroed
-    // and freed (0.2 s); the whole step 34.4 against 33.4 ms.  (The cause lies below the HIP interface -- which
-    // physical pages the driver hands out -- and was not found; staggered or spaced field addresses change
-    // nothing.)  So a context that is about to allocate a large pool takes that much memory once, writes it and
-    // gives it back.  TEDD_PRIME_MEMORY=0 in the environment skips it; a failure here is not an error.
-    static constexpr bool kHasPrime = true;
-    void prime_memory(size_t bytes) {
-        const char* e = std::getenv("TEDD_PRIME_MEMORY");
-        if (e && e[0] == '0') return;
+    // Where the field buffers of a large slab lie in device memory changes the time of the launches that stream
+    // many of them at once, by up to 8 % for the predictor (13 arrays read, 8 written) of a 16384^2 mesh on an
+    // MI355X: 9.0-9.2 ms per launch with the buffers in the first memory a process is given by separate
+    // hipMalloc calls (one after the other in physical memory, every buffer on a 2 GiB boundary), 8.2-8.9 ms
+    // anywhere else, for the whole life of a context.  Counters (rocprofv3, identical launches in a slow and a
+    // fast context of one process): requests, L2 hits and misses, address translations (UTCL1 hits, misses,
+    // UTCL2 busy) all agree to 0.1 %; what moves is the time a read spends between the L2 and the memory
+    // (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ: 1900 against 1710 cycles, +11 %).  A plain streaming kernel of the
+    // same 13 + 8 arrays carved from ONE allocation runs at 5.2 to 6.5 TB/s depending on nothing but the
+    // distance between consecutive arrays (reproducible to 0.2 % inside a process): the slowest distances are
+    // the array's own size, i.e. buffers packed back to back; from about 1.8 times the size on the rate is
+    // within 3 % of the best.  So the buffers of a large slab are carved from one allocation, two buffer sizes
+    // apart, when that much memory is to spare (the gaps stay unused; at most half of the free device memory is
+    // taken), packed back to back otherwise.  TEDD_FIELD_GAP_MB in the environment sets the gap between the end
+    // of one buffer and the start of the next instead (0: packed; -1: separate allocations, no arena).  An
+    // arena that cannot be allocated is not an error: the buffers are then allocated one by one, and
+    // placement() says so.
+    static constexpr bool kHasArena = true;
+    char* arena = nullptr;
+    size_t arena_stride = 0;
+    int arena_slots = 0, arena_used = 0;
+    std::string placement_note = "separate allocations";
+    const char* placement() const { return placement_note.c_str(); }
+    void arena_setup(size_t field_bytes, int slots) {
+        const size_t mb = (size_t)1 << 20;
+        const size_t rounded = (field_bytes + 2 * mb - 1) / (2 * mb) * (2 * mb);
+        long long gap_mb = -2;  // -2: automatic
+        if (const char* e = std::getenv("TEDD_FIELD_GAP_MB")) gap_mb = std::atoll(e);
+        if (gap_mb == -1) return;
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
             (void)hipGetLastError();
+            placement_note = "separate allocations (hipMemGetInfo failed)";
             return;
         }
-        bytes = std::min(bytes, fr - fr / 8);
+        size_t stride = rounded + (gap_mb >= 0 ? (size_t)gap_mb * mb : rounded);
+        if (gap_mb == -2 && stride * slots > fr / 2) stride = rounded;  // no room for the gaps: packed
+        if (stride * slots > fr - fr / 16) {
+            placement_note = "separate allocations (one arena would not fit into the free device memory)";
+            return;
+        }
         void* p = nullptr;
-        if (bytes == 0 || hipMalloc(&p, bytes) != hipSuccess) {
+        const hipError_t err = hipMalloc(&p, stride * slots);
+        if (err != hipSuccess) {
             (void)hipGetLastError();
+            placement_note = std::string("separate allocations (arena refused: ") + hipGetErrorString(err) + ")";
             return;
         }
-        (void)hipMemsetAsync(p, 0, bytes, stream);
-        (void)hipStreamSynchronize(stream);
-        (void)hipFree(p);
-        (void)hipGetLastError();
+        arena = (char*)p;
+        arena_stride = stride;
+        arena_slots = slots;
+        arena_used = 0;
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "one arena of %d buffers, %zu MiB apart (buffer %zu MiB)", slots, stride / mb,
+                      rounded / mb);
+        placement_note = buf;
+    }
+    // a field buffer: the next slot of the arena while it has one, else an allocation of its own
+    void* field_alloc(size_t bytes) {
+        if (arena && arena_used < arena_slots && bytes <= arena_stride) return arena + (size_t)(arena_used++) * arena_stride;
+        return alloc(bytes);
+    }
+    void field_free(void* p) {
+        if (arena && (char*)p >= arena && (char*)p < arena + arena_stride * arena_slots) return;
+        free(p);
+    }
+    void arena_release() {
+        if (arena) (void)hipFree(arena);
+        arena = nullptr;
+        arena_slots = arena_used = 0;
     }
     void* alloc(size_t bytes) {
         void* p = nullptr;

@@ -599,7 +599,8 @@ struct StripArgs {
 // Convergence record of the Newton solves of one step (device memory, `red`):
 //   red[2v], red[2v+1]   max|delta^S - delta^(S-1)| (last update) and max|delta^S| (increment), v = T, cl, cd
 //   red[8+2v]            max|delta^1 - delta^0| of a warm-started solve (first update)
-//   red[16+v]            sticky: worst last_update / (tol * increment) over the steps folded so far
+//   red[9+2v]            max|u| of the lagged unknown, recorded by the first sweep of a warm-started solve
+//   red[16+v]            sticky: worst last_update / max(tol * increment, floor * max|u|) over the steps folded so far
 // The prologue of the next step folds a record into the sticky ratios (systems with tol[v] > 0 only: sweep
 // counts the caller fixed are the caller's responsibility) and publishes it to the host.
 struct StepRecordArgs {
@@ -608,6 +609,10 @@ struct StepRecordArgs {
     double seq;
     double tol[3];
     int fold, clear, cs_iters;
+    // An update below floor x max|u| is far below the rounding of u + delta (floor = 2^-62: 2^-10 of an ulp) and
+    // counts as converged whatever the increment is: on meshes whose time step moves the unknown by less than
+    // 1e-6 of its size, tol x increment alone would ask for updates 1e5 times smaller than an ulp of the unknown.
+    double floor = 0.0;
 };
 TEDD_HD void fold_record(const StepRecordArgs& a, const double* rec, int v) {
     if (!(a.tol[v] > 0.0)) return;
@@ -615,8 +620,12 @@ TEDD_HD void fold_record(const StepRecordArgs& a, const double* rec, int v) {
     double ratio = 0.0;
     if (upd != upd || inc != inc)
         ratio = INFINITY;
-    else if (upd > 0.0)
-        ratio = (inc > 0.0) ? upd / (a.tol[v] * inc) : INFINITY;
+    else if (upd > 0.0) {
+        const double umax = rec[9 + 2 * v];
+        double den = a.tol[v] * inc;
+        if (umax == umax && a.floor * umax > den) den = a.floor * umax;
+        ratio = (den > 0.0) ? upd / den : INFINITY;
+    }
     const double old = a.red[16 + v];
     a.red[16 + v] = (ratio > old || old != old) ? ratio : old;
 }
@@ -626,7 +635,8 @@ TEDD_HD void fold_record(const StepRecordArgs& a, const double* rec, int v) {
 // T -> 0, cl/cd keep their boundary values, prob1base.py:3038-3039, 2102-2106) and report
 // { max|delta_new - delta_in|, max|delta_new| } for the convergence record.
 // MODE JAC_FIRST: first sweep of a warm-started solve: the incoming iterate is not an array but
-// delta^0 = gscale * (u_old - u_prev), the increment of the time step before; reports max|delta^1 - delta^0|.
+// delta^0 = gscale * (u_old - u_prev), the increment of the time step before; reports
+// { max|delta^1 - delta^0|, max|u_old| }.
 enum : int { JAC_PLAIN = 0, JAC_FINAL = 1, JAC_FIRST = 2 };
 template <int VAR, int REACT, int MODE>
 struct JacobiFn {
@@ -673,6 +683,8 @@ struct JacobiFn {
                 const double up = fabs(dn - iterate_in(uo, li, j));
                 red[0] = (up > red[0] || up != up) ? up : red[0];
                 if (up != up) red[0] = INFINITY;
+                const double um = fabs(uo[c]);
+                red[1] = um > red[1] ? um : red[1];
             }
         }
     }

@@ -455,16 +455,27 @@ k_solve_strip(const StripArgs A) {
         // (a batch of loads first, unconditionally, then the masking: a select next to its load is compiled
         // into a branch around the load, and the loads of a thread then wait for each other, one round trip
         // each; batches of kBatch rows keep the loaded values within the register budget)
+        // (the size of the unknown, for the floor of the stopping rule, is taken from the same values: every
+        // entry read is one of the array, clamped coordinates included; fmax drops NaNs, which show in the
+        // other records)
+        double umax = 0.0;
 #pragma unroll
         for (int k0 = 0; k0 < R; k0 += kBatch) {
 #pragma unroll
             for (int k = k0; k < k0 + kBatch; ++k) {
                 const size_t c = (size_t)min(max(row0 + k, 0), rmax) * g.ld + jd;
-                d[k] = (FUSED ? uov[FUSED ? k + 1 : 0] : uo_[c]) - A.u_prev[c];
+                const double uo_v = FUSED ? uov[FUSED ? k + 1 : 0] : uo_[c];
+                d[k] = uo_v - A.u_prev[c];
+                umax = fmax(umax, fabs(uo_v));
             }
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int k = k0; k < k0 + kBatch; ++k) d[k] = is_active(row0 + k) ? A.gscale * d[k] : 0.0;
+        }
+        umax = wave_max_nn(umax);
+        if (lane == 0) {
+            const unsigned long long ubits = (unsigned long long)__double_as_longlong(umax);
+            if (ubits > __atomic_load_n(A.stats_first + 1, __ATOMIC_RELAXED)) atomicMax(A.stats_first + 1, ubits);
         }
     } else if (LEAN) {
     } else if (FUSED || A.d_in == A.b_in) {
@@ -533,8 +544,8 @@ k_solve_strip(const StripArgs A) {
             const double cur = d[k];
             const double v = update(k, prev, cur, (k < R - 1) ? d[k + 1] : below);
             d[k] = v;
-            const int r = R * wave + k;
-            const double up = (lane_in && r >= H && r < TR - H) ? fabs(v - cur) : 0.0;
+            const int r = R * wave + k, li = row0 + k;
+            const double up = (lane_in && r >= H && r < TR - H && li >= A.r0 && li < A.r1) ? fabs(v - cur) : 0.0;
             first_max = (up > first_max || up != up) ? up : first_max;
             prev = cur;
         }

@@ -63,10 +63,12 @@ PROTOTYPES = {
     "tedd_local_rows": (C.c_int32, [C.c_void_p]),
     "tedd_row_offset": (C.c_int32, [C.c_void_p]),
     "tedd_pitch": (C.c_int32, [C.c_void_p]),
+    "tedd_placement": (C.c_char_p, [C.c_void_p]),
     "tedd_set_state": (C.c_int, [C.c_void_p] + [_dptr] * 5),
     "tedd_get_state": (C.c_int, [C.c_void_p] + [_dptr] * 5),
     "tedd_state_device_ptrs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "tedd_ghosts_refreshed": (C.c_int, [C.c_void_p]),
+    "tedd_record_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
     "tedd_prefetch_forcing": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "tedd_set_state_exact": (C.c_int, [C.c_void_p, C.c_double]),
     "tedd_set_forcing": (C.c_int, [C.c_void_p, C.c_int32] + [_dptr] * 5),
@@ -179,6 +181,7 @@ class Context:
         self.nrows = int(self._lib.tedd_local_rows(h))
         self.row_offset = int(self._lib.tedd_row_offset(h))
         self.pitch = int(self._lib.tedd_pitch(h))
+        self.placement = self._lib.tedd_placement(h).decode()
         self.shape = (self.nrows, self.M + 1)
 
     def close(self):
@@ -253,6 +256,12 @@ class Context:
         p = (C.c_void_p * 5)()
         self._check(self._lib.tedd_state_device_ptrs(self._h, p))
         return [int(v) for v in p]
+
+    def record_device_ptr(self):
+        """(address, n): the convergence record of the step in flight in the context's memory (tedd_record_device_ptr)."""
+        p, n = C.c_void_p(), C.c_int32()
+        self._check(self._lib.tedd_record_device_ptr(self._h, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
 
     def ghosts_refreshed(self):
         self._check(self._lib.tedd_ghosts_refreshed(self._h))

@@ -62,6 +62,42 @@ def partition_rows(n_rows: int, world: int, rank: int, ghost: int) -> Slab:
     return Slab(rank, world, n_rows, lo, hi, ghost if world > 1 else 0)
 
 
+def a_priori_sweeps(x, y, consts, dt, jacobi_tol=1e-13, jacobi_max=100000):
+    """Jacobi sweeps per Newton system (T, cl, cd) that the library performs from a zero iterate when the count is
+    left to it: rows of (2 I - dt J) are diagonally dominant with contraction rho <= q / (2 + q),
+    q = dt D max(Cx- + Cx+ + Cy- + Cy+), and ceil(log tol / log rho) + 1 sweeps bring the last update below
+    tol x increment.  x, y: the coordinates of the WHOLE mesh; consts: the 17 model constants in the reference's
+    order (src/prob1base.py:28-45).  Needed before a slab context exists, to size its ghost zone."""
+    import math
+    x = [float(v) for v in x]
+    y = [float(v) for v in y]
+
+    def metric(c):
+        best = 0.0
+        for i in range(1, len(c) - 1):
+            a, b = c[i] - c[i - 1], c[i + 1] - c[i]
+            best = max(best, (1.0 / a + 1.0 / b) / (0.5 * (a + b)))
+        return best
+    q_metric = metric(x) + metric(y)
+    out = []
+    for D in (consts[6], consts[7], consts[12]):       # DT, Dl_max, Dd_max
+        q = dt * abs(float(D)) * q_metric
+        if not q > 0:
+            out.append(2)
+            continue
+        s = math.ceil(math.log(jacobi_tol) / math.log(q / (2.0 + q))) + 1
+        out.append(int(min(max(2, s), jacobi_max)))
+    return out
+
+
+def ghost_rows_needed(sweeps, library_chosen: bool) -> int:
+    """Ghost rows a slab needs for one predictor-corrector step without communication.  Sweep counts fixed by the
+    caller: 1 + their sum.  Counts left to the library (`sweeps` = a_priori_sweeps(...)): their sum + 3 -- a
+    warm-started solve performs all its sweeps after the right-hand side, one stencil application more per system
+    than a solve from zero, and never more sweeps than the a-priori count."""
+    return int(sum(sweeps)) + (3 if library_chosen else 1)
+
+
 _HAS_FOREACH_COPY = hasattr(torch, "_foreach_copy_")
 
 
@@ -80,15 +116,13 @@ class HaloExchange:
     """Refreshes the ghost rows of a list of (local_rows x pitch) tensors with one send and one
     receive per neighbour (all fields packed into one message)."""
 
-    def __init__(self, slab: Slab, group=None, stage_through_host=None):
+    def __init__(self, slab: Slab, group=None):
         self.slab = slab
         self.group = group
         self._bufs = {}
         # group ranks of the slabs below and above (a caller with its own rank numbering may set them)
         self.peer_lo = slab.rank - 1
         self.peer_hi = slab.rank + 1
-        # gloo has no device-memory point-to-point: stage device rows through pinned host buffers
-        self.stage_through_host = stage_through_host
 
     def _buf(self, key, shape, like):
         b = self._bufs.get(key)
@@ -103,11 +137,6 @@ class HaloExchange:
         s = self.slab
         if s.world == 1:
             return
-        stage = self.stage_through_host
-        if stage is None:
-            stage = fields[0].is_cuda and dist.get_backend(self.group) == "gloo"
-        if stage:
-            return self._exchange_staged(fields, before_wait)
         o_lo, o_hi = s.owned_local
         nf = len(fields)
         pitch = fields[0].shape[1]
@@ -136,34 +165,6 @@ class HaloExchange:
             w.wait()
         for recv, a, b in unpack:
             _copy_many([f[a:b] for f in fields], [recv[k] for k in range(nf)])
-
-    def _exchange_staged(self, fields, before_wait=None):
-        s = self.slab
-        o_lo, o_hi = s.owned_local
-        ops, unpack = [], []
-        if s.rank > 0:
-            n_send = min(s.ghost, s.n_rows - s.row_lo)
-            send = torch.stack([f[o_lo:o_lo + n_send] for f in fields]).cpu()
-            recv = torch.empty((len(fields), s.ghost_lo, fields[0].shape[1]), dtype=fields[0].dtype)
-            ops += [dist.P2POp(dist.isend, send, self.peer_lo, self.group),
-                    dist.P2POp(dist.irecv, recv, self.peer_lo, self.group)]
-            unpack.append((recv, 0, s.ghost_lo))
-        if s.rank < s.world - 1:
-            n_send = min(s.ghost, s.row_hi)
-            send = torch.stack([f[o_hi - n_send:o_hi] for f in fields]).cpu()
-            recv = torch.empty((len(fields), s.ghost_hi, fields[0].shape[1]), dtype=fields[0].dtype)
-            ops += [dist.P2POp(dist.isend, send, self.peer_hi, self.group),
-                    dist.P2POp(dist.irecv, recv, self.peer_hi, self.group)]
-            unpack.append((recv, o_hi, o_hi + s.ghost_hi))
-        works = dist.batch_isend_irecv(ops)
-        if before_wait is not None:
-            before_wait()
-        for w in works:
-            w.wait()
-        for recv, a, b in unpack:
-            r = recv.to(fields[0].device)
-            for k, f in enumerate(fields):
-                f[a:b].copy_(r[k])
 
 
 class _DeviceArray:
@@ -212,30 +213,41 @@ class SlabStepper:
     corrector), the HCsTriple corrector's ValueError and the verdict on the Jacobi solves through
     `check_converged`, which every rank must call at the same points."""
 
+    halo_cls = HaloExchange
+
     def __init__(self, ctx, slab: Slab, device, group=None):
         self.ctx = ctx
         self.slab = slab
         self.device = device
         self.group = group
-        self.halo = HaloExchange(slab, group)
+        self.halo = self.halo_cls(slab, group)
         self._wrapped = {}
+        self._record = None
         if device.type == "cuda":
             ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
         if slab.world > 1:
             ctx.set_reduce_hook(self._reduce_record)
 
+    def _all_reduce(self, tensor, op):
+        """In-place all-reduce over the slabs of a tensor that lives where the context's memory lives (RCCL on
+        device tensors, ordered on the current stream, which is the context's; gloo on host tensors)."""
+        dist.all_reduce(tensor, op=op, group=self.group)
+
     def _reduce_record(self, pmax, pmin, n):
-        tmax = _wrap_vector(pmax, n, self.device)
-        tmin = _wrap_vector(pmin, n, self.device)
-        if tmax.is_cuda and dist.get_backend(self.group) == "gloo":   # no device collectives: through the host
-            hmax, hmin = tmax.cpu(), tmin.cpu()
-            dist.all_reduce(hmax, op=dist.ReduceOp.MAX, group=self.group)
-            dist.all_reduce(hmin, op=dist.ReduceOp.MIN, group=self.group)
-            tmax.copy_(hmax)
-            tmin.copy_(hmin)
-        else:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=self.group)
-            dist.all_reduce(tmin, op=dist.ReduceOp.MIN, group=self.group)
+        self._all_reduce(_wrap_vector(pmax, n, self.device), dist.ReduceOp.MAX)
+        self._all_reduce(_wrap_vector(pmin, n, self.device), dist.ReduceOp.MIN)
+
+    def _share_solve_record(self):
+        """The library chooses sweep counts and warm starts of later steps from the convergence record of this one
+        (maxima over the context's rows).  Replacing every entry by its maximum over the slabs makes all ranks take
+        the decisions one context holding the whole mesh would take: equal counts on every rank, hence equal
+        consumption of ghost rows, and the iteration of the single-domain run."""
+        if self.slab.world == 1:
+            return
+        if self._record is None:
+            ptr, n = self.ctx.record_device_ptr()
+            self._record = _wrap_vector(ptr, n, self.device)
+        self._all_reduce(self._record, dist.ReduceOp.MAX)
 
     def _fields(self):
         # the state arrays rotate through a small pool of device buffers: wrap each address once
@@ -256,6 +268,7 @@ class SlabStepper:
 
     def step_pc(self, t0, dt, **kw):
         self.ctx.step_pc(t0, dt, **kw)
+        self._share_solve_record()
         # the forcing of the step after this one does not depend on the state: its launch goes to the
         # compute stream while the ghost rows travel (the next step starts at t0 + dt and needs the
         # levels t0 + dt, which is kept, and (t0 + dt) + dt)
@@ -277,10 +290,8 @@ class SlabStepper:
             err = e
         if self.slab.world > 1:
             code = 0 if err is None else (1 if isinstance(err, ValueError) else 2)
-            flag = torch.tensor([code], dtype=torch.int32)
-            if dist.get_backend(self.group) != "gloo":
-                flag = flag.to(self.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            flag = torch.tensor([code], dtype=torch.int32, device=self.device)
+            self._all_reduce(flag, dist.ReduceOp.MAX)
             worst = int(flag.item())
             if err is None and worst:
                 err = (ValueError if worst == 1 else RuntimeError)("another slab reported: " + (

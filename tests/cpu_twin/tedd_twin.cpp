@@ -17,7 +17,7 @@ namespace tedd {
 struct CpuBackend {
     static constexpr bool kHasStripSolve = false;
     static constexpr bool kHasPersist = false;
-    static constexpr bool kHasPrime = false;
+    static constexpr bool kHasArena = false;
     static constexpr bool kHasCodegen = false;
     void rec_begin(int, int) {}
     void rec_end() {}
@@ -32,6 +32,8 @@ struct CpuBackend {
     void set_stream(void*) {}
     void* alloc(size_t bytes) { return std::calloc(bytes ? bytes : 1, 1); }
     void free(void* p) { std::free(p); }
+    void* field_alloc(size_t bytes) { return alloc(bytes); }
+    void field_free(void* p) { free(p); }
     void memset0(void* p, size_t bytes) { std::memset(p, 0, bytes); }
     // The row loops run under OpenMP on meshes large enough to pay for it (the CPU-baseline leg of the
     // benchmark times this library on one core and on all cores); the small meshes of the tests stay
@@ -58,6 +60,7 @@ struct CpuBackend {
                 a.ring_slot[1 + v] = rec[2 * v];
                 a.ring_slot[4 + v] = rec[2 * v + 1];
                 a.ring_slot[7 + v] = rec[8 + 2 * v];
+                a.ring_slot[10 + v] = rec[9 + 2 * v];
             }
             a.ring_slot[0] = a.seq;
         }

@@ -85,8 +85,11 @@ def _worker(rank, world, port, case, N, M, nsteps, kind, consts, sweeps, ghost, 
         stepper.check_converged()
         state = ctx.get_state()
         a, b = slab.owned_local
+        st = ctx.get_stats()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=slab.row_lo, hi=slab.row_hi,
-                 norms=np.array(norms), cs_iterations=ctx.get_stats()["cs_iterations"],
+                 norms=np.array(norms), cs_iterations=st["cs_iterations"], sweeps=np.array(st["sweeps"]),
+                 warm=np.array(st["warm_started"]), increment=np.array(st["increment"]),
+                 first_update=np.array(st["first_update"]),
                  **{f"f{k}": s[a:b] for k, s in enumerate(state)})
         ctx.close()
     finally:
@@ -112,7 +115,10 @@ def _single(case, N, M, nsteps, kind, consts, sweeps, step_kw=None):
         t += dt
         norms.append(ctx.error_norms(t))
     out = ctx.get_state()
-    _single.cs_iterations = ctx.get_stats()["cs_iterations"]
+    st = ctx.get_stats()
+    _single.cs_iterations = st["cs_iterations"]
+    _single.sweeps, _single.warm = list(st["sweeps"]), list(st["warm_started"])
+    _single.increment, _single.first_update = list(st["increment"]), list(st["first_update"])
     ctx.close()
     return out, np.array(norms)
 
@@ -142,6 +148,41 @@ def test_slab_run_equals_single_domain(world, kind, case, consts, options, tmp_p
         np.testing.assert_allclose(z["norms"], ref_norms, rtol=1e-12, atol=1e-300)
         rows += hi - lo
     assert rows == N + 1
+
+
+# (on this mesh the T system needs ~25 sweeps from zero: the warm start pays, and the library changes its sweep
+# counts in the course of the run from the convergence records)
+WARM_T = list(NB_A)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_run_with_library_chosen_sweeps_equals_single_domain(world, tmp_path):
+    """Sweep counts and warm starts left to the library (jacobi_sweeps = None) over 12 steps: the slabs share the
+    convergence record of every step (one MAX all-reduce), take the decisions of the single-domain run and
+    reproduce its states bit for bit; ghost = sum of the a-priori counts + 3."""
+    from bench import pick_sweeps
+    N, M, nsteps = 127, 21, 12
+    x = np.linspace(0, 1, N + 1) ** 1.1
+    y = np.linspace(0, 1, M + 1)
+    cold = pick_sweeps(N, 0.01, 1e-13, x=x, y=y, consts=WARM_T)
+    assert cold[0] >= 15, cold
+    ghost = sum(cold) + 3
+    assert (N + 1) // world >= ghost, (cold, ghost)
+    ref_state, ref_norms = _single(1, N, M, nsteps, "pc", WARM_T, None)
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, 1, N, M, nsteps, "pc", WARM_T, None, ghost, str(tmp_path), {}),
+             nprocs=world, join=True)
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        lo, hi = int(z["lo"]), int(z["hi"])
+        for k in range(5):
+            np.testing.assert_array_equal(z[f"f{k}"], ref_state[k][lo:hi])   # bit for bit
+        np.testing.assert_allclose(z["norms"], ref_norms, rtol=1e-12, atol=1e-300)
+        # the counts the library ended up with are those of the single-domain run, warm start included
+        assert list(z["sweeps"]) == _single.sweeps and list(z["warm"]) == _single.warm
+        # ... and every rank holds the record of the whole mesh (maxima over all slabs), not that of its rows
+        assert list(z["increment"]) == _single.increment and list(z["first_update"]) == _single.first_update
+    assert _single.warm[0] == 1 and _single.sweeps[0] < cold[0]
 
 
 def _positive_state(N, M):

@@ -46,7 +46,8 @@ def _worker(rank, world, port, out_dir, options):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from tedd import _ffi
-        from tedd.distributed import SlabStepper, partition_rows
+        from tedd.distributed import partition_rows
+        from gloo_staging import HostStagedSlabStepper as SlabStepper
         torch.cuda.set_device(0)
         x = np.linspace(0, 1, N + 1)
         y = np.linspace(0, 1, M + 1)

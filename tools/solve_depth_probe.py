@@ -29,3 +29,15 @@ for s in (1, 2, 3, 4, 6, 8, 10):
     ctx.profile_enable(False)
     print(s, " ".join("%s=%.3f" % (k, v["total_ms"] / v["launches"]) for k, v in prof.items() if k.startswith("solve")), flush=True)
 ctx.close()
+
+# the record of the warm-started solves of an ordinary run (sweep counts chosen by the library)
+ctx = _ffi.Context(x, x, bench.consts_vec(bench.NB_A), model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+                   mms_case=_ffi.MMS_EXPSIN)
+ctx.set_state_exact(0.0)
+for k in range(14):
+    ctx.step_pc(k * dt, dt)
+    st = ctx.get_stats()
+    print(k, "sweeps", st["sweeps"], "warm", st["warm_started"], "first/inc",
+          ["%.2e" % (f / i if i else 0) for f, i in zip(st["first_update"], st["increment"])], "last/inc",
+          ["%.2e" % (u / i if i else 0) for u, i in zip(st["last_update"], st["increment"])], flush=True)
+ctx.close()
