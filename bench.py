@@ -37,7 +37,6 @@ sys.path.insert(0, os.path.join(ROOT, "na-nonlinear-temperature-enhanced-diffusi
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (8 TB/s)
-PMC_PROFILE_TAG = "r02"  # prefix of the committed counter summaries that describe the kernels of this tree
 
 NB_A = dict(R0=8.3144621, Ea=1.60217662e-19, K1=1e-3, K2=1e-3, K3=1e-3, K4=1e-3, DT=1e-3,
             Dl_max=1e-5, phi_l=1e-5, gamma_T=1e-9, Kd=1e-2, Sd=1, Dd_max=1e-6, phi_d=1e-5,
@@ -101,18 +100,45 @@ FAMILY_KERNELS = {"predict": ["PredictFn"], "forcing": ["ForcingFn"], "cs_newton
                   "jacobi_T": ["JacobiFn<1,"], "jacobi_cl": ["JacobiFn<2,"], "jacobi_cd": ["JacobiFn<3,"]}
 
 
-def pmc_traffic(fam, config):
-    """HBM bytes per launch of a family from the committed PMC summary of this same configuration
-    (profiles/*_pmc_<N>.json, written by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE
+def library_stamp(library=None):
+    """What identifies the kernels a measurement ran: SHA-256 of the library file and of the sources it is built
+    from (csrc/ and include/tedd.h, in name order)."""
+    import hashlib
+    pkg = os.path.join(ROOT, "na-nonlinear-temperature-enhanced-diffusion-model-dd_amd")
+    lib = library or os.path.join(pkg, "lib", "libtedd_hip.so")
+    srcs = sorted(os.path.join(pkg, "csrc", f) for f in os.listdir(os.path.join(pkg, "csrc")))
+    srcs.append(os.path.join(ROOT, "include", "tedd.h"))
+    hs = hashlib.sha256()
+    for path in srcs:
+        with open(path, "rb") as fh:
+            hs.update(os.path.basename(path).encode() + b"\0" + fh.read())
+    with open(lib, "rb") as fh:
+        hl = hashlib.sha256(fh.read()).hexdigest()
+    fresh = all(os.path.getmtime(lib) >= os.path.getmtime(p) for p in srcs)
+    return {"library_sha256": hl, "source_sha256": hs.hexdigest(), "library_not_older_than_sources": fresh}
+
+
+def pmc_traffic(fam, config, library=None, profiles_dir=None):
+    """HBM bytes per launch of a family from a committed PMC summary of this same configuration AND this same
+    library (profiles/*pmc_<N>.json, written by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE
     passes): (2 x FETCH_SIZE + WRITE_SIZE) KB -- on gfx950 FETCH_SIZE tallies the 128-byte requests
-    of coalesced streaming reads at 64 bytes.  None if no summary matches the configuration."""
+    of coalesced streaming reads at 64 bytes.  A summary is used only if its stamp names the library file that is
+    being timed (or, after a rebuild, the same sources with a library not older than they are); otherwise the
+    traffic is unknown: {"bytes_per_launch": None, "note": why}."""
     import glob
-    # only summaries of the kernels of this tree: the counter passes of earlier rounds measured other kernels
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{PMC_PROFILE_TAG}_*pmc_{config['mesh_N']}.json")),
-                       reverse=True):
+    now = library_stamp(library)
+    seen = 0
+    pdir = profiles_dir or os.path.join(ROOT, "profiles")
+    for path in sorted(glob.glob(os.path.join(pdir, f"*pmc_{config['mesh_N']}.json")), reverse=True):
         with open(path) as fh:
             summ = json.load(fh)
         if any(summ.get("config", {}).get(k) != config[k] for k in ("mesh_N", "solver", "sweeps_per_launch", "forcing")):
+            continue
+        stamp = summ.get("stamp") or {}
+        same_lib = stamp.get("library_sha256") == now["library_sha256"]
+        same_src = stamp.get("source_sha256") == now["source_sha256"] and now["library_not_older_than_sources"]
+        if not (same_lib or same_src):
+            seen += 1
             continue
         tot, launches = 0.0, 0
         for name, c in summ["kernels"].items():
@@ -121,8 +147,12 @@ def pmc_traffic(fam, config):
                 tot += (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024.0 * n
                 launches += n
         if launches:
-            return {"bytes_per_launch": tot / launches, "source": os.path.relpath(path, ROOT)}
-    return None
+            return {"bytes_per_launch": tot / launches, "source": os.path.relpath(path, ROOT),
+                    "stamp": {"library_sha256": stamp.get("library_sha256"), "git_rev": stamp.get("git_rev"),
+                              "matched": "library file" if same_lib else "sources (library rebuilt)"}}
+    return {"bytes_per_launch": None, "source": None,
+            "note": f"no counter summary under profiles/ was taken with this library ({seen} of this configuration "
+                    f"carry another stamp); library sha256 {now['library_sha256'][:16]}"}
 
 
 def consts_vec(d):
@@ -475,11 +505,14 @@ def main():
     cfg_key = {"mesh_N": N, "solver": args.solver, "sweeps_per_launch": args.hmax, "forcing": forcing_mode,
                "jacobi_sweeps": list(sweeps)}
     if roofline is not None and world == 1:   # the committed counter passes are whole-mesh launches on one GPU
-        tr = pmc_traffic(fam, cfg_key)
-        if tr is not None:
-            roofline["traffic"] = tr["bytes_per_launch"]
-            roofline["traffic_source"] = tr["source"]
-            roofline["algorithmic_bytes_per_launch"] = 8.0 * n_nodes_local * arrays.get(fam, 0)
+        tr = pmc_traffic(fam, cfg_key, args.library)
+        roofline["traffic"] = tr["bytes_per_launch"]
+        roofline["traffic_source"] = tr["source"]
+        if tr["bytes_per_launch"] is None:
+            roofline["traffic_note"] = tr["note"]
+        else:
+            roofline["traffic_stamp"] = tr["stamp"]
+        roofline["algorithmic_bytes_per_launch"] = 8.0 * n_nodes_local * arrays.get(fam, 0)
     units = args.steps * (world if weak else 1)
     mesh_txt = (f"{rows_global - 1}x{N}-cell mesh on [0,{world}]x[0,1] ({nodes_all} nodes, a {N}-row slab per rank)"
                 if weak else f"{N}x{N}-cell mesh ({nodes_all} nodes)")

@@ -265,6 +265,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KREG <
     constexpr int kCsReg = KREG;
     const bool in_regs = (iters <= kCsReg);
     double rmx[kCsReg], rmn[kCsReg];
+    int first_bad = 0x7fffffff;  // first iteration at which some node of this thread held a NaN
 #pragma unroll
     for (int k = 0; k < kCsReg; ++k) {
         rmx[k] = 0.0;
@@ -318,11 +319,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KREG <
                     const double dx = cs_newton_step(x, y, av, a.m.eta, ex);
                     x = x + dx;
                     if (k + 1 < keep) ex = cs_newton_exp_next(ex, x, dx, a.m.eta);
-                    double adx = fabs(dx), ax = fabs(x);
-                    if (adx != adx) adx = INFINITY;
-                    if (ax != ax) ax = 0.0;
-                    rmx[k] = adx > rmx[k] ? adx : rmx[k];
-                    rmn[k] = ax < rmn[k] ? ax : rmn[k];
+                    cs_record_update(dx, x, k, rmx[k], rmn[k], first_bad);
                 }
             }
         } else {
@@ -357,7 +354,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KREG <
 #pragma unroll
         for (int k = 0; k < kCsReg; ++k) {
             if (k < iters) {
-                const double wmx = wave_max_nn(rmx[k]), wmn = wave_min_nn(rmn[k]);  // (no NaN among them: replaced per node)
+                cs_record_finish(k, rmx[k], rmn[k], first_bad);
+                const double wmx = wave_max_nn(rmx[k]), wmn = wave_min_nn(rmn[k]);  // (no NaN among them)
                 if ((int)threadIdx.x == k) {
                     mine_mx = wmx;
                     mine_mn = wmn;
@@ -1289,8 +1287,12 @@ struct HipBackend {
             constexpr bool WM = decltype(warm_c)::value;
             constexpr bool FU = decltype(fused_c)::value;
             constexpr bool XF = decltype(xface_c)::value;
+            // (a warm single-launch chain of long T strips parks the lagged unknown of the rows it writes in LDS)
+            size_t lds = 0;
+            if (LAST && WM && VAR == VAR_T && StripShape<VAR, SH>::R > 4 && !FU)
+                lds = (size_t)(std::max(StripShape<VAR, SH>::TR - 2 * A.H, 0) + 1) * kSTile * sizeof(double);
             hipLaunchKernelGGL((k_solve_strip<VAR, REACT, LAST, SH, WM, FU, XF>), dim3((unsigned)nt),
-                               dim3(kSTile, StripShape<VAR, SH>::W), 0, stream, A);
+                               dim3(kSTile, StripShape<VAR, SH>::W), lds, stream, A);
         };
         auto by_warm = [&](auto shape_c, auto fused_c, auto xface_c) {
             if (warm)

@@ -825,6 +825,23 @@ TEDD_HD double cs_newton_step(double x, double y, double av, double eta, double 
     return tedd_div(-f, J);
 }
 TEDD_HD double cs_newton_exp(double x, double eta) { return exp(-eta * x); }
+// Per-thread record of iteration k over the nodes a thread visits: rmx = max|dx| with a NaN counted as +inf,
+// rmn = min|x| with a NaN counted as 0.  fmax / fmin drop NaNs, so the NaN is remembered apart, as the first
+// iteration whose x was one (a compare, a select and an integer minimum instead of four compare-and-select
+// pairs per iteration): a NaN in dx makes x = x + dx a NaN and every later x and dx with it, and x can become a
+// NaN without dx being one only as inf - inf, where |dx| = inf is in the maximum already.
+TEDD_HD void cs_record_update(double dx, double x, int k, double& rmx, double& rmn, int& first_bad) {
+    rmx = fmax(rmx, fabs(dx));
+    rmn = fmin(rmn, fabs(x));
+    const int kb = (x != x) ? k : 0x7fffffff;
+    first_bad = kb < first_bad ? kb : first_bad;
+}
+TEDD_HD void cs_record_finish(int k, double& rmx, double& rmn, int first_bad) {
+    if (k >= first_bad) {
+        rmx = INFINITY;
+        rmn = 0.0;
+    }
+}
 // e^{-eta (x + dx)} from ex = e^{-eta x}: the iteration converges quadratically, so after its first update
 // |eta dx| is far below 2^-10 and the six-term series of e^{-eta dx} is exact to rounding; the library
 // routine serves the values beyond that (value by value the result does not depend on the other lanes).

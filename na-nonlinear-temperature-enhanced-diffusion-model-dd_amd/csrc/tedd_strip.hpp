@@ -233,6 +233,13 @@ k_solve_strip(const StripArgs A) {
     // at the write-back, where nothing else is left to hide that round trip behind.
     constexpr bool UOLD_EARLY = LAST && LEAN && R <= 4 && !FUSED;
     double uold_e[UOLD_EARLY ? R : 1];
+    // A warm-started chain of long strips that is a single launch reads the lagged unknown twice: for its
+    // starting iterate and, after the sweeps, to add the increment to.  There are no registers to carry 16 values
+    // across the sweeps, so each thread parks them in LDS (the rows the tile writes back only: dynamic shared
+    // memory of (TR - 2H + 1) x 64 doubles, 26 KB at depth 7, four tiles per compute unit still fit) and reads its own
+    // words back at the write-back: one array pass fewer (no barrier: a thread reads what it wrote itself).
+    constexpr bool USTASH = LAST && WARM && LEAN && R > 4 && !FUSED;
+    extern __shared__ double ustash[];
     // The record words this launch may raise at its very end, read now: most tiles find at the end that they do
     // not raise them, without a round trip there (a value read too early is too small: one atomic more, never
     // one fewer).
@@ -455,10 +462,10 @@ k_solve_strip(const StripArgs A) {
         // (a batch of loads first, unconditionally, then the masking: a select next to its load is compiled
         // into a branch around the load, and the loads of a thread then wait for each other, one round trip
         // each; batches of kBatch rows keep the loaded values within the register budget)
-        // (the size of the unknown, for the floor of the stopping rule, is taken from the same values: every
-        // entry read is one of the array, clamped coordinates included; fmax drops NaNs, which show in the
-        // other records)
-        double umax = 0.0;
+        // (parked values: byte offset of the thread's row k = 0 in the stash; rows the tile does not write back go
+        // to a spare row -- a select, no branch that would split the batch of loads)
+        const int sbase = (R * wave - H) * (kSTile * 8) + lane * 8;
+        const int sdummy = TIR * (kSTile * 8) + lane * 8;
 #pragma unroll
         for (int k0 = 0; k0 < R; k0 += kBatch) {
 #pragma unroll
@@ -466,16 +473,15 @@ k_solve_strip(const StripArgs A) {
                 const size_t c = (size_t)min(max(row0 + k, 0), rmax) * g.ld + jd;
                 const double uo_v = FUSED ? uov[FUSED ? k + 1 : 0] : uo_[c];
                 d[k] = uo_v - A.u_prev[c];
-                umax = fmax(umax, fabs(uo_v));
+                if (USTASH) {
+                    const int r = R * wave + k;
+                    const int off = (r >= H && r < TR - H) ? sbase + k * (kSTile * 8) : sdummy;
+                    *reinterpret_cast<double*>(reinterpret_cast<char*>(ustash) + off) = uo_v;
+                }
             }
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int k = k0; k < k0 + kBatch; ++k) d[k] = is_active(row0 + k) ? A.gscale * d[k] : 0.0;
-        }
-        umax = wave_max_nn(umax);
-        if (lane == 0) {
-            const unsigned long long ubits = (unsigned long long)__double_as_longlong(umax);
-            if (ubits > __atomic_load_n(A.stats_first + 1, __ATOMIC_RELAXED)) atomicMax(A.stats_first + 1, ubits);
         }
     } else if (LEAN) {
     } else if (FUSED || A.d_in == A.b_in) {
@@ -495,7 +501,7 @@ k_solve_strip(const StripArgs A) {
     TEDD_STAMP(2);
     // which of this thread's nodes are written back
     const bool lane_in = (lane >= HC && lane < kSTile - HC && j >= 0 && j < g.ncols);
-    double up_max = 0.0, mag_max = 0.0;
+    double up_max = 0.0, mag_max = 0.0, u_max = 0.0;
 
     // ---- sweeps.  The last launch of a chain keeps its final sweep for the write-back below.
     int par = 0;
@@ -597,7 +603,11 @@ k_solve_strip(const StripArgs A) {
     int row0w = row0, jw = j;
     asm volatile("" : "+s"(row0w));
     asm volatile("" : "+v"(jw));
+    int wave_w = wave, lane_w = lane;
+    asm volatile("" : "+s"(wave_w));
+    asm volatile("" : "+v"(lane_w));
     double cs_rmx[CORR ? kStripCsRegs : 1], cs_rmn[CORR ? kStripCsRegs : 1];
+    int cs_first_bad = 0x7fffffff;
     if (CORR) {
 #pragma unroll
         for (int q = 0; q < kStripCsRegs; ++q) {
@@ -616,7 +626,13 @@ k_solve_strip(const StripArgs A) {
                     uold[k - k0] = uov[FUSED ? k + 1 : 0];
                 else if (UOLD_EARLY)
                     uold[k - k0] = uold_e[UOLD_EARLY ? k : 0];
-                else
+                else if (USTASH) {
+                    // (addresses rebuilt from laundered coordinates: kept from the set-up they would be sixteen
+                    // registers across the sweeps)
+                    const int r = R * wave_w + k;
+                    const int off = (r >= H && r < TR - H) ? (r - H) * (kSTile * 8) + lane_w * 8 : TIR * (kSTile * 8) + lane_w * 8;
+                    uold[k - k0] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ustash) + off);
+                } else
                     uold[k - k0] = uo[(size_t)min(max(row0w + k, 0), rmax) * g.ld + min(max(jw, 0), g.ncols - 1)];
             }
             asm volatile("" ::: "memory");
@@ -632,6 +648,7 @@ k_solve_strip(const StripArgs A) {
                         unew = uold[k - k0] + d[k];
                         const double mag = fabs(d[k]);
                         mag_max = (mag > mag_max || mag != mag) ? mag : mag_max;
+                        if (WARM) u_max = fmax(u_max, fabs(unew));  // (size of the unknown: floor of the stopping rule)
                     } else {
                         unew = (VAR == VAR_T) ? 0.0 : uold[k - k0];
                     }
@@ -649,11 +666,7 @@ k_solve_strip(const StripArgs A) {
                                 const double dx = cs_newton_step(x, y, av, m.eta, ex);
                                 x = x + dx;
                                 if (q + 1 < A.cs_iters) ex = cs_newton_exp_next(ex, x, dx, m.eta);
-                                double adx = fabs(dx), ax = fabs(x);
-                                if (adx != adx) adx = INFINITY;
-                                if (ax != ax) ax = 0.0;
-                                cs_rmx[CORR ? q : 0] = adx > cs_rmx[CORR ? q : 0] ? adx : cs_rmx[CORR ? q : 0];
-                                cs_rmn[CORR ? q : 0] = ax < cs_rmn[CORR ? q : 0] ? ax : cs_rmn[CORR ? q : 0];
+                                cs_record_update(dx, x, q, cs_rmx[CORR ? q : 0], cs_rmn[CORR ? q : 0], cs_first_bad);
                             }
                         }
                         put_once(A.cs_out + c, in ? x : 0.0 * x);
@@ -678,6 +691,7 @@ k_solve_strip(const StripArgs A) {
 #pragma unroll
         for (int q = 0; q < kStripCsRegs; ++q) {
             if (q < A.cs_iters) {
+                cs_record_finish(q, cs_rmx[CORR ? q : 0], cs_rmn[CORR ? q : 0], cs_first_bad);
                 const double wmx = wave_max_nn(cs_rmx[CORR ? q : 0]), wmn = wave_min_nn(cs_rmn[CORR ? q : 0]);
                 if (lane == q) {
                     mine_mx = wmx;
@@ -709,7 +723,19 @@ k_solve_strip(const StripArgs A) {
             red[2 * wave] = up_max;
             red[2 * wave + 1] = mag_max;
         }
+        if (WARM) {
+            // a single-launch warm chain also records the size of the unknown, next to its first update
+            // (fmax drops NaNs, which show in the other records)
+            u_max = wave_max_nn(u_max);
+            if (lane == 0) red[2 * W + wave] = u_max;
+        }
         __syncthreads();
+        if (WARM && wave == 0 && lane == 2) {
+            double v = red[2 * W];
+            for (int w2 = 1; w2 < W; ++w2) v = fmax(v, red[2 * W + w2]);
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+            if (bits > __atomic_load_n(A.stats_first + 1, __ATOMIC_RELAXED)) atomicMax(A.stats_first + 1, bits);
+        }
         if (wave == 0 && lane < 2) {
             double v = red[lane];
             for (int w2 = 1; w2 < W; ++w2) {

@@ -37,10 +37,41 @@ def test_sweep_counts_follow_the_contraction_bound():
         assert bench.pick_sweeps(N, (1.0 / N) ** 1.5, 1e-13) == expect
 
 
-def test_committed_pmc_summary_feeds_the_traffic_figure():
+def test_traffic_is_quoted_only_from_counter_passes_of_the_library_that_is_timed(tmp_path):
+    """roofline.traffic comes from a committed summary of rocprofv3 counter passes; a summary is used only if its
+    stamp names the library being timed (or the same sources after a rebuild) -- otherwise the figure is null, with
+    a note, never a number measured on other kernels."""
+    cfg = {"mesh_N": 16384, "solver": "strip", "sweeps_per_launch": 10, "forcing": "arrays per time level"}
+    now = bench.library_stamp()
+    kb = 16385 * 16385 * 8 / 1024.0
+    summ = {"config": dict(cfg), "stamp": {"library_sha256": "0" * 64, "source_sha256": "1" * 64, "git_rev": "abc"},
+            "kernels": {"void tedd::k_march<tedd::PredictFn<-1, 1, -1>, 2, true>(...)":
+                        {"FETCH_SIZE": {"mean": 13.2 * kb / 2, "n": 4}, "WRITE_SIZE": {"mean": 8.0 * kb, "n": 4}}}}
+    path = tmp_path / "rXX_pmc_16384.json"
+    path.write_text(json.dumps(summ))
+    tr = bench.pmc_traffic("predict", cfg, profiles_dir=str(tmp_path))
+    assert tr["bytes_per_launch"] is None and tr["source"] is None and "another stamp" in tr["note"]
+    summ["stamp"]["library_sha256"] = now["library_sha256"]        # the very library file
+    path.write_text(json.dumps(summ))
+    tr = bench.pmc_traffic("predict", cfg, profiles_dir=str(tmp_path))
+    assert tr["bytes_per_launch"] == pytest.approx(21.2 * 16385 * 16385 * 8) and tr["stamp"]["matched"] == "library file"
+    summ["stamp"] = {"library_sha256": "0" * 64, "source_sha256": now["source_sha256"], "git_rev": "abc"}
+    path.write_text(json.dumps(summ))
+    tr = bench.pmc_traffic("predict", cfg, profiles_dir=str(tmp_path))
+    if now["library_not_older_than_sources"]:                       # same sources, library rebuilt since
+        assert tr["bytes_per_launch"] is not None and tr["stamp"]["matched"].startswith("sources")
+    else:
+        assert tr["bytes_per_launch"] is None
+    assert bench.pmc_traffic("predict", dict(cfg, mesh_N=123), profiles_dir=str(tmp_path))["bytes_per_launch"] is None
+
+
+def test_committed_pmc_summary_of_this_library_is_plausible():
+    """If the tree holds the counter summary of its own library (the round's final profiles), every launch family's
+    traffic is within a few per cent of its algorithmic bytes."""
     cfg = {"mesh_N": 16384, "solver": "strip", "sweeps_per_launch": 10, "forcing": "arrays per time level"}
     tr = bench.pmc_traffic("predict", cfg)
-    assert tr is not None and tr["source"].startswith("profiles/" + bench.PMC_PROFILE_TAG)
+    if tr["bytes_per_launch"] is None:
+        pytest.skip(tr["note"])
     algorithmic = 8.0 * 16385 * 16385 * 21
     assert algorithmic < tr["bytes_per_launch"] < 1.05 * algorithmic     # every array row is read once
     # (the right-hand sides march with their next row travelling into LDS: the two 16-byte granules a wave asks for
@@ -48,7 +79,6 @@ def test_committed_pmc_summary_feeds_the_traffic_figure():
     for fam, arrays, slack in (("rhs_cl", 7, 1.08), ("rhs_cd", 10, 1.08), ("forcing", 5, 1.05), ("cs_newton", 8, 1.05)):
         got = bench.pmc_traffic(fam, cfg)["bytes_per_launch"]
         assert 0.99 * arrays < got / (8.0 * 16385 * 16385) < slack * arrays, fam
-    assert bench.pmc_traffic("predict", dict(cfg, mesh_N=123)) is None
 
 
 @pytest.mark.gpu

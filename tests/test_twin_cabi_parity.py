@@ -13,8 +13,12 @@ from tedd import _ffi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TWIN_DIR = os.path.join(ROOT, "tests", "cpu_twin")
-TWIN = os.path.join(TWIN_DIR, "libtedd_twin.so")
+# TEDD_TWIN_SANITIZE=1: every test that uses the twin runs on its AddressSanitizer + UndefinedBehaviorSanitizer
+# build (the process must have been started with the sanitizer runtime preloaded: tests/test_twin_sanitized.py)
+SANITIZE = os.environ.get("TEDD_TWIN_SANITIZE") == "1"
+TWIN = os.path.join(TWIN_DIR, "libtedd_twin_asan.so" if SANITIZE else "libtedd_twin.so")
 CSRC = os.path.join(ROOT, "na-nonlinear-temperature-enhanced-diffusion-model-dd_amd", "csrc")
+SANITIZE_FLAGS = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
 
 
 def build_twin():
@@ -22,8 +26,9 @@ def build_twin():
     srcs.append(os.path.join(ROOT, "include", "tedd.h"))
     if os.path.exists(TWIN) and all(os.path.getmtime(TWIN) >= os.path.getmtime(s) for s in srcs):
         return
-    subprocess.check_call(["g++", "-O2", "-fopenmp", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC, "-o", TWIN,
-                           os.path.join(TWIN_DIR, "tedd_twin.cpp")])
+    opt = SANITIZE_FLAGS if SANITIZE else ["-O2"]
+    subprocess.check_call(["g++"] + opt + ["-fopenmp", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC, "-o", TWIN,
+                                           os.path.join(TWIN_DIR, "tedd_twin.cpp")])
 
 
 @pytest.fixture(scope="module", autouse=True)

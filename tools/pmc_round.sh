@@ -1,5 +1,6 @@
 # Counter passes of the bench configuration (16384^2), one rocprofv3 run per pass (the passes cannot share a
-# run), summarised by tools/pmc_summary.py.  Run on the GPU box from the repository root.
+# run), summarised by tools/pmc_summary.py.  Run on the GPU box from the repository root; TEDD_GIT_REV (the
+# revision of the tree that was sent, the box has no .git) goes into the summary's stamp beside the library's hash.
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc
 mkdir -p $OUT

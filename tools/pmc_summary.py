@@ -2,12 +2,18 @@
 
 usage: pmc_summary.py out.json mesh_N solver sweeps_per_launch forcing_mode pass1.csv [pass2.csv ...]
 (forcing_mode: the string bench.py prints in config.forcing)
+The summary is stamped with the hash of the library the passes ran (and of its sources, and with $TEDD_GIT_REV
+if set): bench.py quotes a summary's traffic only for that same library.
 The second launch of the cs-Newton kernel in a step returns at once (no early exit): its near-zero
 samples are dropped."""
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (library_stamp)
 
 out, mesh, solver, hmax, forcing = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -23,5 +29,6 @@ for k, v in agg.items():
         kernels[k][c] = {"mean": sum(xs) / len(xs), "n": len(xs)}
 json.dump({"config": {"mesh_N": mesh, "solver": solver, "sweeps_per_launch": hmax,
                       "forcing": forcing},
+           "stamp": dict(bench.library_stamp(), git_rev=os.environ.get("TEDD_GIT_REV")),
            "units": {"FETCH_SIZE": "KB (x2 on gfx950 for coalesced streaming reads)", "WRITE_SIZE": "KB"},
            "kernels": kernels}, open(out, "w"), indent=1)
