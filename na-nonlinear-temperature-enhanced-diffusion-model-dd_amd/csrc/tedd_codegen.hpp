@@ -93,6 +93,12 @@ inline std::string gen_source(const HostProg& node, const HostProg& cell, int re
     std::string s;
     s += "#include \"tedd_prog.hpp\"\n";
     s += "using namespace tedd;\n";
+    // the headers found at run time must be those this library was built from: the kernels receive GridDev, ModelC,
+    // ProgAxes and Out5 by value from code compiled here
+    s += "static_assert(kProgContractVersion == " + std::to_string(kProgContractVersion) +
+         " && sizeof(GridDev) == " + std::to_string(sizeof(GridDev)) + " && sizeof(ModelC) == " + std::to_string(sizeof(ModelC)) +
+         " && sizeof(ProgAxes) == " + std::to_string(sizeof(ProgAxes)) + " && sizeof(Out5) == " + std::to_string(sizeof(Out5)) +
+         ", \"the headers beside the library are not the ones it was built from\");\n";
     s += "struct GenEval {\n";
     s += "    __device__ __forceinline__ void node(double t, double x, double y, double* out) const {\n";
     s += "        double r0 = t, r1 = x, r2 = y;\n        (void)r0; (void)r1; (void)r2;\n";
@@ -185,11 +191,12 @@ inline const std::vector<char>& gen_compile(const std::string& src, const std::s
     static std::mutex mu;
     static std::map<std::string, std::vector<char>> cache;
     std::lock_guard<std::mutex> lk(mu);
-    const std::string key = arch + "\n" + src;
+    // (the header directory is part of the key: the same source against another tree is another program)
+    const std::string inc = "-I" + gen_include_dir();
+    const std::string key = arch + "\n" + inc + "\n" + src;
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     const HiprtcApi& rtc = HiprtcApi::get();
-    const std::string inc = "-I" + gen_include_dir();
     const std::string march = "--offload-arch=" + arch;
     hiprtcProgram prog = nullptr;
     if (rtc.create(&prog, src.c_str(), "tedd_generated_mms.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)

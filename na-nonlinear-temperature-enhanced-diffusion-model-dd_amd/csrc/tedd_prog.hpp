@@ -30,6 +30,13 @@
 
 namespace tedd {
 
+// Version of the contract between the prebuilt library and the kernels it generates and compiles at run time against
+// THIS header tree (argument structures passed by value, prog_forcing_node / prog_exact_node): raise it with any
+// change to that contract.  The generated source asserts the value and the structure sizes the library was built
+// with, so that a header tree that does not belong to the library fails to compile (and the interpreter is used).
+constexpr int kProgContractVersion = 1;
+
+
 enum ProgOp : int {
     POP_CONST = 0, POP_ADD, POP_SUB, POP_MUL, POP_DIV, POP_NEG, POP_POWI, POP_POW, POP_EXP, POP_SIN, POP_COS,
     POP_SQRT, POP_LOG, POP_ABS, POP_SIGN, POP_TANH, POP_OUT, POP_MOV, POP_COUNT

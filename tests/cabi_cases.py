@@ -401,6 +401,54 @@ def check_generated_kernels_equal_interpreter(react, which):
         c.close()
 
 
+def check_skewed_header_tree_is_refused(tmp_dir):
+    """The generated kernels are compiled at run time against the headers beside the library (or under
+    $TEDD_CSRC_DIR) and take their argument structures by value from the prebuilt library.  A header tree that is not
+    the library's own -- here a copy with another contract version -- must fail to compile: prog_codegen = 1 reports
+    it, prog_codegen = -1 keeps the interpreter and its arrays."""
+    import shutil
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(_ffi.__file__))), "csrc")
+    skew = os.path.join(str(tmp_dir), "csrc")
+    shutil.copytree(csrc, skew)
+    path = os.path.join(skew, "tedd_prog.hpp")
+    text = open(path).read()
+    assert "constexpr int kProgContractVersion = " in text
+    import re
+    text = re.sub(r"constexpr int kProgContractVersion = (\d+);",
+                  lambda m: f"constexpr int kProgContractVersion = {int(m.group(1)) + 1000};", text)
+    open(path, "w").write(text)
+    x, y, consts, node, cell = expsin_programs()
+    kw = dict(model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0)
+    ref = _ffi.Context(x, y, consts, mms_case=_ffi.MMS_PROGRAM, **kw)
+    ref.set_option("prog_codegen", 0)
+    ref.set_mms_program(0, *node)
+    ref.set_mms_program(1, *cell)
+    want = ref.eval_forcing(0.3)
+    old = os.environ.get("TEDD_CSRC_DIR")
+    os.environ["TEDD_CSRC_DIR"] = skew
+    try:
+        strict = _ffi.Context(x, y, consts, mms_case=_ffi.MMS_PROGRAM, **kw)
+        strict.set_option("prog_codegen", 1)
+        strict.set_mms_program(0, *node)
+        strict.set_mms_program(1, *cell)
+        with pytest.raises(ValueError, match="not the ones it was built from"):
+            strict.eval_forcing(0.3)
+        strict.close()
+        lenient = _ffi.Context(x, y, consts, mms_case=_ffi.MMS_PROGRAM, **kw)
+        lenient.set_option("prog_codegen", -1)
+        lenient.set_mms_program(0, *node)
+        lenient.set_mms_program(1, *cell)
+        for p_, r_ in zip(lenient.eval_forcing(0.3), want):
+            np.testing.assert_array_equal(p_, r_)
+        lenient.close()
+    finally:
+        if old is None:
+            os.environ.pop("TEDD_CSRC_DIR", None)
+        else:
+            os.environ["TEDD_CSRC_DIR"] = old
+    ref.close()
+
+
 # ---------------------------------------------------------------------------------- sub-steps
 REACT_OF = {"reg": _ffi.REACT_REGHCSTRIPLE, "cs3": _ffi.REACT_CSTRIPLE, "hcs": _ffi.REACT_HCSTRIPLE}
 

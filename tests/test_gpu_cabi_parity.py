@@ -155,6 +155,10 @@ def test_generated_program_kernels_equal_interpreter(react, which):
     cc.check_generated_kernels_equal_interpreter(react, which)
 
 
+def test_generated_kernels_refuse_a_header_tree_that_is_not_the_librarys(tmp_path):
+    cc.check_skewed_header_tree_is_refused(tmp_path)
+
+
 # ---- the pieces of a predictor-corrector step called on their own
 @pytest.mark.parametrize("streamed", [False, True], ids=["closed_form", "streamed"])
 @pytest.mark.parametrize("tag", cc.tags("golden_substeps.npz", "/t0"))

@@ -24,8 +24,11 @@ def test_noalloc_norms_equal_the_allocating_entry_point():
     from tedd import _ffi
     assert torch.cuda.is_available()
     out = torch.full((8,), float("nan"), dtype=torch.float64, device="cuda:0")
-    big = _context(700, 333, _ffi.MMS_EXPSIN)       # 176 x 6 tiles x ... > 2048 workgroups: every partial slot is written
-    small = _context(37, 21, _ffi.MMS_PEAKS, (1.0, 10.0))  # 10 workgroups: leaves most slots holding the sums of `big`
+    # 1101 x 521 nodes are 276 x 9 = 2484 tiles of 4 x 64 nodes, more than the 2048 workgroups the reduction
+    # launches: every slot of the static array is written and the workgroups stride over the tiles
+    big = _context(1100, 520, _ffi.MMS_EXPSIN)
+    # a handful of workgroups: leaves nearly all slots holding the sums of `big`
+    small = _context(37, 21, _ffi.MMS_PEAKS, (1.0, 10.0))
     try:
         for ctx, steps in ((big, 3), (small, 2), (big, 1)):
             dt = 1e-3
