@@ -342,6 +342,9 @@ def parse_args(argv=None):
     ap.add_argument("--mesh", type=int, default=16384, help="N of the (N+1)^2-node synthetic mesh")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong: one N x N mesh split over the ranks; weak: an N-row slab per rank")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="several ranks: wait for the ghost rows after every step instead of letting them travel under "
+                         "the next step's first launch")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for CPU rehearsals)")
     ap.add_argument("--device", choices=["cuda", "cpu"], default="cuda",
                     help="cpu: drive a host-compiled library given with --library (rehearsal of the multi-rank path)")
@@ -423,7 +426,7 @@ def main():
     ctx = _ffi.Context(x, y, consts_vec(NB_A), model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
                        mms_case=_ffi.MMS_EXPSIN, row_lo=slab.row_lo, row_hi=slab.row_hi, ghost=slab.ghost,
                        device=local_rank if on_gpu else -1)
-    stepper = SlabStepper(ctx, slab, device)
+    stepper = SlabStepper(ctx, slab, device, overlap=not args.no_overlap)
     ctx.set_option("strip_solve", 1 if args.solver == "strip" else 0)
     ctx.set_option("cache_forcing", args.cache_forcing)
     ctx.set_option("fuse_forcing", args.fuse_forcing)
@@ -451,11 +454,13 @@ def main():
         stepper.step_pc(t, dt, **kw)
         t += dt
     ctx.profile_enable(True)
+    stepper.finish()      # (the timed region posts and completes the ghost-row exchanges of exactly its own steps)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stepper.step_pc(t, dt, **kw)
         t += dt
+    stepper.finish()
     barrier()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_get()
@@ -530,7 +535,10 @@ def main():
                    "forcing": forcing_mode,
                    "value_counts": ("time steps of the whole mesh" if not weak else
                                     "time steps of one rank's slab, summed over the ranks"),
-                   "parallelism": f"row slabs x{world}, ghost={slab.ghost}", "error_H_after_run": err_H},
+                   "parallelism": f"row slabs x{world}, ghost={slab.ghost}" + (", ghost rows travel under the next step's predictor"
+                                                                          if stepper.overlap else ""),
+                   "field_placement": ctx.placement,
+                   "error_H_after_run": err_H},
         "roofline": roofline,
         "step_hbm": {"algorithmic_arrays_per_step": arrays_step, "achieved_GBps_all_gpus": step_gbs,
                      "frac_of_peak": step_gbs / (HBM_PEAK_GBS * world)},

@@ -292,6 +292,19 @@ int tedd_set_reduce_hook(tedd_ctx* ctx, tedd_reduce_fn fn, void* user);
  * holding the whole mesh would take. */
 int tedd_record_device_ptr(tedd_ctx* ctx, void** ptr, int32_t* n);
 
+/* Ghost rows in flight.  On a decomposed mesh the ghost rows of the new state travel between the slabs after every
+ * step (no counterpart in the reference, which is one process).  A driver that does not want to wait for them calls
+ * tedd_ghosts_pending after it has posted the transfer: the context then treats the ghost rows of the current state
+ * as not yet valid.  The next tedd_step_pc runs its first launch (the predictor, the largest of the step) on the rows
+ * whose stencils do not reach into the ghost zone, calls the ghost hook -- which must complete the transfer into the
+ * arrays of tedd_state_device_ptrs, by work ordered on the context's stream, and return 0 -- and then runs that
+ * launch on the two remaining bands and the rest of the step: the transfer overlaps the bulk of the predictor.
+ * Without a hook, tedd_ghosts_refreshed ends the pending state; any other use of a state whose ghost rows are
+ * pending is TEDD_ERR_INVALID. */
+typedef int (*tedd_ghost_fn)(void* user);
+int tedd_set_ghost_hook(tedd_ctx* ctx, tedd_ghost_fn fn, void* user);
+int tedd_ghosts_pending(tedd_ctx* ctx);
+
 /* Per-kernel device timing with HIP events on the context's stream.  enable != 0 starts
  * recording (and clears the totals).  tedd_profile_get returns, for up to `cap` kernel families,
  * the name, the number of launches and the summed milliseconds; returns the number of families. */

@@ -153,6 +153,19 @@ int tedd_record_device_ptr(tedd_ctx* ctx, void** ptr, int32_t* n) {
 int tedd_prefetch_forcing(tedd_ctx* ctx, double t, double keep_t) {
     return guarded(ctx, [&](auto& C) { C.prefetch_forcing(t, keep_t); });
 }
+int tedd_set_ghost_hook(tedd_ctx* ctx, tedd_ghost_fn fn, void* user) {
+    return guarded(ctx, [&](auto& C) {
+        C.ghost_hook = fn;
+        C.ghost_user = user;
+    });
+}
+int tedd_ghosts_pending(tedd_ctx* ctx) {
+    return guarded(ctx, [&](auto& C) {
+        C.require_state();
+        if (C.gl == 0 && C.gr == 0) throw tedd::InvalidError("a context that holds the whole mesh has no ghost rows");
+        C.ghost_pending = true;
+    });
+}
 int tedd_ghosts_refreshed(tedd_ctx* ctx) {
     return guarded(ctx, [&](auto& C) { C.mark_state_exchanged(); });
 }

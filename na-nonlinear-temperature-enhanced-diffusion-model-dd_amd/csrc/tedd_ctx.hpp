@@ -628,12 +628,14 @@ public:
             if (!cur[v]) cur[v] = acquire();
     }
     void set_state(const double* const h[5]) {
+        ghost_pending = false;
         ensure_state_buffers();
         for (int v = 0; v < 5; ++v) upload_field(cur[v], h[v]);
         reset_history();
     }
     void get_state(double* const h[5]) {
         require_state();
+        refuse_pending_ghosts("tedd_get_state");
         be.d2h_fields(h, cur, 5, ld, ncols, nrows);
     }
     // Install nxt as the state; buffers of the old state that are not reused go back to the pool.
@@ -664,6 +666,24 @@ public:
     void mark_state_exchanged() {
         require_state();
         for (int v = 0; v < 5; ++v) mark(cur[v], full());
+        ghost_pending = false;
+    }
+    // Ghost rows in flight (tedd_ghosts_pending): the driver posted their transfer and did not wait.  The first
+    // launch of the next predictor-corrector step runs on the rows that do not need them, then the hook completes
+    // the transfer, then the launch runs on the remaining bands.
+    tedd_ghost_fn ghost_hook = nullptr;
+    void* ghost_user = nullptr;
+    bool ghost_pending = false;
+    void complete_pending_ghosts() {
+        if (!ghost_pending) return;
+        if (!ghost_hook) throw InvalidError("the ghost rows of the state are in flight: refresh them (tedd_ghosts_refreshed) or set a ghost hook");
+        if (ghost_hook(ghost_user) != 0) throw std::runtime_error("the ghost hook failed");
+        mark_state_exchanged();
+    }
+    void refuse_pending_ghosts(const char* what) const {
+        if (ghost_pending)
+            throw InvalidError(std::string(what) + ": the ghost rows of the state are in flight (tedd_ghosts_pending); complete "
+                               "the exchange and call tedd_ghosts_refreshed first");
     }
 
     // ------------------------------------------------------------------ dispatch helpers
@@ -738,6 +758,7 @@ public:
     };
     void eval_field(double t, double* const h[5]) {
         require_state();
+        refuse_pending_ghosts("tedd_eval_field");
         Tmp5 tmp(this);
         FieldOp op{this, t, 0.0, false, {tmp.p[0], tmp.p[1], tmp.p[2], tmp.p[3], tmp.p[4]}};
         dispatch(op);
@@ -747,6 +768,7 @@ public:
     }
     void step_feuler(double t0, double dt) {
         require_state();
+        refuse_pending_ghosts("tedd_step_feuler");
         release_retained();
         double* nxt[5];
         for (int v = 0; v < 5; ++v) nxt[v] = acquire();
@@ -789,6 +811,7 @@ public:
         be.sync();
     }
     void set_state_exact(double t) {
+        ghost_pending = false;
         ensure_state_buffers();
         ExactOp op{this, t, {cur[0], cur[1], cur[2], cur[3], cur[4]}};
         dispatch(op);
@@ -825,6 +848,7 @@ public:
     }
     void eval_jacobian(int opid, double* const h[5]) {
         require_state();
+        refuse_pending_ghosts("tedd_eval_jacobian");
         if (opid < 0 || opid > 5) throw InvalidError("jacobian op must be 0..5");
         Tmp5 tmp(this);
         Out5 o;
@@ -891,6 +915,7 @@ public:
     static constexpr long long kNoallocMaxNodes = 1LL << 26;
     void error_norms_noalloc(double t, double* dev_out) {
         require_state();
+        refuse_pending_ghosts("tedd_error_norms_noalloc");
         if (!dev_out) throw InvalidError("out is null");
         if (mms_case == CASE_STREAM || mms_case == CASE_PROG)
             throw InvalidError("tedd_error_norms_noalloc needs a closed-form MMS case (the others keep the exact "
@@ -902,6 +927,7 @@ public:
     }
     void error_norms_async(double t, double* dev_out) {
         require_state();
+        refuse_pending_ghosts("tedd_error_norms");
         NormOp op{this, t, dev_out};
         dispatch(op);
     }
@@ -1506,8 +1532,29 @@ public:
         double* ncp = grab();  // t0 parts of the correctors
         double* ycs = grab();
         {
-            Range r = need({{cur[0], true}, {cur[1], true}, {cur[2], true}, {cur[3], true}, {cur[4], false},
-                            {fcp_t0, false}});
+            auto pred_range = [&]() {
+                return need({{cur[0], true}, {cur[1], true}, {cur[2], true}, {cur[3], true}, {cur[4], false}, {fcp_t0, false}});
+            };
+            Range r = pred_range();
+            // Ghost rows in flight: the launch runs on the rows it can serve now, the hook brings the ghost rows,
+            // then the launch runs on the bands that were left out (same functor, same values: the node results
+            // do not depend on how the rows are dealt to launches).
+            auto launch_split = [&](auto&& one_launch) {
+                if (!ghost_pending) {
+                    one_launch(r.lo, r.hi);
+                    return;
+                }
+                const Range ri = r;
+                if (ri.hi > ri.lo) one_launch(ri.lo, ri.hi);
+                complete_pending_ghosts();
+                r = pred_range();
+                if (ri.hi <= ri.lo) {
+                    one_launch(r.lo, r.hi);
+                    return;
+                }
+                if (r.lo < ri.lo) one_launch(r.lo, ri.lo);
+                if (ri.hi < r.hi) one_launch(ri.hi, r.hi);
+            };
             // the register-resident solve iterates on b = rhs/diag; for the first T system the predictor
             // kernel has everything b needs
             double* bT = nullptr;
@@ -1525,7 +1572,7 @@ public:
                         PredictFn<CASE_STREAM, REACT, decltype(fcase)::value> f{
                             g, model, tb, f0, f1c, fields(cur), YT, Ycl, Ycd, cpP, csP, fcp_t0, fcp_t0_out,
                             fcp_t1_out, dt, bT, ncp, ycs, fo};
-                        launch_predictor(f, r.lo, r.hi);
+                        launch_split([&](int lo, int hi) { launch_predictor(f, lo, hi); });
                     };
                     switch (mms_case) {
                         case CASE_POL: launch(std::integral_constant<int, CASE_POL>{}); break;
@@ -1541,7 +1588,7 @@ public:
             if (!launched) {
                 PredictFn<CASE, REACT> f{g, model, tb, f0, f1, fields(cur), YT, Ycl, Ycd, cpP, csP, fcp_t0, fcp_t0_out,
                                          fcp_t1_out, dt, bT, ncp, ycs, Out5{}};
-                launch_predictor(f, r.lo, r.hi);
+                launch_split([&](int lo, int hi) { launch_predictor(f, lo, hi); });
             }
             for (double* q : {YT, Ycl, Ycd, cpP, csP, ncp, ycs}) mark(q, r);
             if (bT) mark(bT, r);
@@ -1767,6 +1814,7 @@ public:
     void substep(int what, double t0, double dt, const double* const in[3], double* const out[2], int cs_iters,
                  double cs_rtol, int sweeps, double jtol, int jmax) {
         require_state();
+        refuse_pending_ghosts("a sub-step");
         if (!(dt > 0)) throw AssertError("dt must be > 0");
         if (what < 0 || what > 4) throw InvalidError("unknown sub-step");
         if (cs_iters < 0 || cs_iters > 4096) throw InvalidError("cs_newton_iterations must be in [0, 4096]");
@@ -1905,6 +1953,7 @@ public:
     void advance(double t0, double dt, int nsteps, int integrator, int num_pc, int num_newton, int cs_iters,
                  double cs_rtol, const int32_t* sweeps, double jtol, int jmax, double* series) {
         require_state();
+        refuse_pending_ghosts("tedd_advance");
         if (nsteps < 0) throw InvalidError("nsteps < 0");
         if (mms_case == CASE_STREAM) throw InvalidError("tedd_advance needs a closed-form MMS case");
         if ((gl > 0 || gr > 0) && nsteps > 1)

@@ -48,6 +48,8 @@ class TeddStepStats(C.Structure):
 
 # int (*tedd_reduce_fn)(void* user, double* dev_max, double* dev_min, int32_t n)
 REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32)
+# int (*tedd_ghost_fn)(void* user)
+GHOST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 
 # name -> (restype, argtypes); every symbol include/tedd.h declares
@@ -93,6 +95,8 @@ PROTOTYPES = {
     "tedd_get_stats": (C.c_int, [C.c_void_p, C.POINTER(TeddStepStats)]),
     "tedd_check_converged": (C.c_int, [C.c_void_p]),
     "tedd_set_reduce_hook": (C.c_int, [C.c_void_p, REDUCE_FN, C.c_void_p]),
+    "tedd_set_ghost_hook": (C.c_int, [C.c_void_p, GHOST_FN, C.c_void_p]),
+    "tedd_ghosts_pending": (C.c_int, [C.c_void_p]),
     "tedd_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "tedd_profile_get": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), _dptr]),
 }
@@ -356,6 +360,29 @@ class Context:
 
         self._reduce_cb = REDUCE_FN(trampoline)   # keep it alive as long as the library may call it
         self._check(self._lib.tedd_set_reduce_hook(self._h, self._reduce_cb, None))
+
+    def set_ghost_hook(self, fn):
+        """fn() -> None completes the transfer of the ghost rows that ghosts_pending() declared in flight, or None to
+        remove the hook (tedd_set_ghost_hook).  An exception raised by fn fails the step and is re-raised."""
+        if fn is None:
+            self._ghost_cb = None
+            self._check(self._lib.tedd_set_ghost_hook(self._h, C.cast(None, GHOST_FN), None))
+            return
+
+        def trampoline(_user):
+            try:
+                fn()
+                return 0
+            except BaseException as e:  # noqa: BLE001 -- must not propagate through the C frames
+                self._hook_error = e
+                return 1
+
+        self._ghost_cb = GHOST_FN(trampoline)
+        self._check(self._lib.tedd_set_ghost_hook(self._h, self._ghost_cb, None))
+
+    def ghosts_pending(self):
+        """The driver posted the transfer of the current state's ghost rows and did not wait (tedd_ghosts_pending)."""
+        self._check(self._lib.tedd_ghosts_pending(self._h))
 
     # -- parity hooks
     def eval_field(self, t):

@@ -131,40 +131,65 @@ class HaloExchange:
             self._bufs[key] = b
         return b
 
-    def exchange(self, fields, before_wait=None):
-        """before_wait: called after the sends and receives are posted and before they are waited for
-        (work to enqueue on the compute stream that may run while the rows travel)."""
+    # the message of one neighbour: the rows [a, b) of every field, packed into one buffer / unpacked from one
+    def _pack(self, key, fields, a, b):
+        send = self._buf(key, (len(fields), b - a, fields[0].shape[1]), fields[0])
+        _copy_many([send[k] for k in range(len(fields))], [f[a:b] for f in fields])
+        return send
+
+    def _recv_buffer(self, key, fields, rows):
+        return self._buf(key, (len(fields), rows, fields[0].shape[1]), fields[0])
+
+    def _unpack(self, recv, fields, a, b):
+        _copy_many([f[a:b] for f in fields], [recv[k] for k in range(len(fields))])
+
+    def post(self, fields):
+        """Packs and posts the sends and receives of one exchange (one message per neighbour) and returns what
+        complete() needs.  Nothing is waited for."""
         s = self.slab
         if s.world == 1:
-            return
+            return None
         o_lo, o_hi = s.owned_local
-        nf = len(fields)
-        pitch = fields[0].shape[1]
-        ops, unpack = [], []
+        ops, unpack, sends = [], [], []
         # lower neighbour: it needs my first `its ghost_hi` owned rows; I need `ghost_lo` rows from it
         if s.rank > 0:
             n_send = min(s.ghost, s.n_rows - s.row_lo)  # = neighbour's ghost_hi
-            send = self._buf("send_lo", (nf, n_send, pitch), fields[0])
-            _copy_many([send[k] for k in range(nf)], [f[o_lo:o_lo + n_send] for f in fields])
-            recv = self._buf("recv_lo", (nf, s.ghost_lo, pitch), fields[0])
+            send = self._pack("send_lo", fields, o_lo, o_lo + n_send)
+            sends.append(send)
+            recv = self._recv_buffer("recv_lo", fields, s.ghost_lo)
             ops.append(dist.P2POp(dist.isend, send, self.peer_lo, self.group))
             ops.append(dist.P2POp(dist.irecv, recv, self.peer_lo, self.group))
             unpack.append((recv, 0, s.ghost_lo))
         if s.rank < s.world - 1:
             n_send = min(s.ghost, s.row_hi)  # = neighbour's ghost_lo
-            send = self._buf("send_hi", (nf, n_send, pitch), fields[0])
-            _copy_many([send[k] for k in range(nf)], [f[o_hi - n_send:o_hi] for f in fields])
-            recv = self._buf("recv_hi", (nf, s.ghost_hi, pitch), fields[0])
+            send = self._pack("send_hi", fields, o_hi - n_send, o_hi)
+            sends.append(send)
+            recv = self._recv_buffer("recv_hi", fields, s.ghost_hi)
             ops.append(dist.P2POp(dist.isend, send, self.peer_hi, self.group))
             ops.append(dist.P2POp(dist.irecv, recv, self.peer_hi, self.group))
             unpack.append((recv, o_hi, o_hi + s.ghost_hi))
-        works = dist.batch_isend_irecv(ops)
-        if before_wait is not None:
-            before_wait()
+        return dist.batch_isend_irecv(ops), unpack, list(fields), sends   # (the messages stay alive until complete())
+
+    def complete(self, posted):
+        """Waits for a posted exchange (over RCCL: makes the current stream wait for it) and writes the received rows
+        into the ghost rows of the fields it was posted for."""
+        if posted is None:
+            return
+        works, unpack, fields, _sends = posted
         for w in works:
             w.wait()
         for recv, a, b in unpack:
-            _copy_many([f[a:b] for f in fields], [recv[k] for k in range(nf)])
+            self._unpack(recv, fields, a, b)
+
+    def exchange(self, fields, before_wait=None):
+        """before_wait: called after the sends and receives are posted and before they are waited for
+        (work to enqueue on the compute stream that may run while the rows travel)."""
+        posted = self.post(fields)
+        if posted is None:
+            return
+        if before_wait is not None:
+            before_wait()
+        self.complete(posted)
 
 
 class _DeviceArray:
@@ -215,7 +240,10 @@ class SlabStepper:
 
     halo_cls = HaloExchange
 
-    def __init__(self, ctx, slab: Slab, device, group=None):
+    def __init__(self, ctx, slab: Slab, device, group=None, overlap=False):
+        """overlap: step_pc posts the exchange of the new state's ghost rows and returns without waiting; the next
+        step_pc runs its first launch on the rows that do not need them while they travel (the context calls back
+        for the rows, tedd_set_ghost_hook).  Call finish() before anything else reads the state."""
         self.ctx = ctx
         self.slab = slab
         self.device = device
@@ -223,10 +251,24 @@ class SlabStepper:
         self.halo = self.halo_cls(slab, group)
         self._wrapped = {}
         self._record = None
+        self._posted = None
+        self.overlap = bool(overlap) and slab.world > 1
         if device.type == "cuda":
             ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
         if slab.world > 1:
             ctx.set_reduce_hook(self._reduce_record)
+        if self.overlap:
+            ctx.set_ghost_hook(self._complete_posted)
+
+    def _complete_posted(self):
+        posted, self._posted = self._posted, None
+        self.halo.complete(posted)
+
+    def finish(self):
+        """Completes an exchange that step_pc left in flight (overlap mode); a no-op otherwise."""
+        if self._posted is not None:
+            self._complete_posted()
+            self.ctx.ghosts_refreshed()
 
     def _all_reduce(self, tensor, op):
         """In-place all-reduce over the slabs of a tensor that lives where the context's memory lives (RCCL on
@@ -263,25 +305,33 @@ class SlabStepper:
     def refresh_ghosts(self, before_wait=None):
         if self.slab.world == 1:
             return
+        self.finish()
         self.halo.exchange(self._fields(), before_wait=before_wait)
         self.ctx.ghosts_refreshed()
 
     def step_pc(self, t0, dt, **kw):
-        self.ctx.step_pc(t0, dt, **kw)
+        self.ctx.step_pc(t0, dt, **kw)      # (overlap mode: completes the exchange of the step before on its way)
         self._share_solve_record()
         # the forcing of the step after this one does not depend on the state: its launch goes to the
         # compute stream while the ghost rows travel (the next step starts at t0 + dt and needs the
         # levels t0 + dt, which is kept, and (t0 + dt) + dt)
         t1 = t0 + dt
-        self.refresh_ghosts(before_wait=lambda: self.ctx.prefetch_forcing(t1 + dt, t1))
+        if self.overlap:
+            self._posted = self.halo.post(self._fields())
+            self.ctx.ghosts_pending()
+            self.ctx.prefetch_forcing(t1 + dt, t1)
+        else:
+            self.refresh_ghosts(before_wait=lambda: self.ctx.prefetch_forcing(t1 + dt, t1))
 
     def step_feuler(self, t0, dt):
+        self.finish()
         self.ctx.step_feuler(t0, dt)
         self.refresh_ghosts()
 
     def check_converged(self):
         """Collective: raises on EVERY rank if the Jacobi solves of some step missed their tolerance on any slab
         (RuntimeError), or the HCsTriple corrector met a non-positive denominator on any slab (ValueError)."""
+        self.finish()
         err = None
         try:
             self.ctx.get_stats()         # raises the corrector's ValueError of this slab

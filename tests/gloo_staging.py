@@ -8,37 +8,24 @@ from tedd.distributed import HaloExchange, SlabStepper
 
 
 class HostStagedHaloExchange(HaloExchange):
-    def exchange(self, fields, before_wait=None):
-        s = self.slab
-        if s.world == 1:
-            return
+    """Messages live in host memory: packed by a device-to-host copy, unpacked by a host-to-device copy."""
+
+    def _pack(self, key, fields, a, b):
         if not fields[0].is_cuda:
-            return super().exchange(fields, before_wait)
-        o_lo, o_hi = s.owned_local
-        ops, unpack = [], []
-        if s.rank > 0:
-            n_send = min(s.ghost, s.n_rows - s.row_lo)
-            send = torch.stack([f[o_lo:o_lo + n_send] for f in fields]).cpu()
-            recv = torch.empty((len(fields), s.ghost_lo, fields[0].shape[1]), dtype=fields[0].dtype)
-            ops += [dist.P2POp(dist.isend, send, self.peer_lo, self.group),
-                    dist.P2POp(dist.irecv, recv, self.peer_lo, self.group)]
-            unpack.append((recv, 0, s.ghost_lo))
-        if s.rank < s.world - 1:
-            n_send = min(s.ghost, s.row_hi)
-            send = torch.stack([f[o_hi - n_send:o_hi] for f in fields]).cpu()
-            recv = torch.empty((len(fields), s.ghost_hi, fields[0].shape[1]), dtype=fields[0].dtype)
-            ops += [dist.P2POp(dist.isend, send, self.peer_hi, self.group),
-                    dist.P2POp(dist.irecv, recv, self.peer_hi, self.group)]
-            unpack.append((recv, o_hi, o_hi + s.ghost_hi))
-        works = dist.batch_isend_irecv(ops)
-        if before_wait is not None:
-            before_wait()
-        for w in works:
-            w.wait()
-        for recv, a, b in unpack:
-            r = recv.to(fields[0].device)
-            for k, f in enumerate(fields):
-                f[a:b].copy_(r[k])
+            return super()._pack(key, fields, a, b)
+        return torch.stack([f[a:b] for f in fields]).cpu()
+
+    def _recv_buffer(self, key, fields, rows):
+        if not fields[0].is_cuda:
+            return super()._recv_buffer(key, fields, rows)
+        return torch.empty((len(fields), rows, fields[0].shape[1]), dtype=fields[0].dtype)
+
+    def _unpack(self, recv, fields, a, b):
+        if not fields[0].is_cuda:
+            return super()._unpack(recv, fields, a, b)
+        r = recv.to(fields[0].device)
+        for k, f in enumerate(fields):
+            f[a:b].copy_(r[k])
 
 
 class HostStagedSlabStepper(SlabStepper):

@@ -38,6 +38,8 @@ def _run(ctx, stepper=None):
         else:
             stepper.step_pc(t, dt, jacobi_sweeps=SWEEPS)
         t += dt
+    if stepper is not None:
+        stepper.finish()
     return ctx.get_state()
 
 
@@ -54,9 +56,12 @@ def _worker(rank, world, port, out_dir, options):
         slab = partition_rows(N + 1, world, rank, sum(SWEEPS) + 2)
         ctx = _ffi.Context(x, y, NB_A, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
                            mms_case=_ffi.MMS_EXPSIN, row_lo=slab.row_lo, row_hi=slab.row_hi, ghost=slab.ghost)
+        options = dict(options)
+        overlap = bool(options.pop("_overlap", False))
         for name, value in options.items():
             ctx.set_option(name, value)
-        state = _run(ctx, SlabStepper(ctx, slab, torch.device("cuda", 0)))
+        stepper = SlabStepper(ctx, slab, torch.device("cuda", 0), overlap=overlap)
+        state = _run(ctx, stepper)
         a, b = slab.owned_local
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=slab.row_lo, hi=slab.row_hi,
                  **{f"f{k}": s[a:b] for k, s in enumerate(state)})
@@ -67,7 +72,9 @@ def _worker(rank, world, port, out_dir, options):
 
 # forcing_launch: the forcing arrays come from a launch of their own, enqueued by the slab stepper while the
 # ghost rows travel (the configuration of slabs too large for the predictor launch to make them)
-@pytest.mark.parametrize("options", [{}, {"fuse_forcing": 0}], ids=["default", "forcing_launch"])
+# overlap: the ghost rows of a step travel while the next step's predictor runs on the rows that do not need them
+@pytest.mark.parametrize("options", [{}, {"fuse_forcing": 0}, {"_overlap": True}, {"_overlap": True, "fuse_forcing": 0}],
+                         ids=["default", "forcing_launch", "overlap", "overlap-forcing_launch"])
 def test_two_slabs_equal_single_slab(tmp_path, options):
     from tedd import _ffi
     _ffi.use_library(_ffi.DEFAULT_LIBRARY)
