@@ -134,7 +134,12 @@ int tedd_set_mms_program(tedd_ctx* ctx, int32_t which, const uint32_t* code, int
  * source, compiled for the context's device at first use (hiprtc; the headers under ../csrc beside the library,
  * or under $TEDD_CSRC_DIR, are included) and run as ordinary kernels with the program registers in VGPRs --
  * -1: where that succeeds, the interpreter otherwise; 1: or TEDD_ERR_INVALID with the compiler's message;
- * 0: interpreter only -- bit-identical arrays either way, about twice the steps per second on a 256^2 mesh. */
+ * 0: interpreter only -- bit-identical arrays either way, about twice the steps per second on a 256^2 mesh;
+ * "jacobi_floor" (default 2^-62; 0 switches it off): floor of the stopping rule of the Newton solves relative to the
+ * size of the unknown -- a last update below jacobi_floor x max|u| counts as converged whatever the increment is
+ * (2^-10 of an ulp of the unknown).  It binds only where jacobi_tol x increment is smaller still, i.e. where a
+ * time step moves the unknown by less than jacobi_floor / jacobi_tol (2e-6) of its size, and only for
+ * warm-started solves, which record max|u|. */
 int tedd_set_option(tedd_ctx* ctx, const char* name, double value);
 /* Use the caller's HIP stream (hipStream_t passed as void*) for all subsequent work. */
 int tedd_set_stream(tedd_ctx* ctx, void* hip_stream);
@@ -178,8 +183,8 @@ int tedd_prefetch_forcing(tedd_ctx* ctx, double t, double keep_t);
  * (src/prob1base.py:3117-3149 with 2953-3115, 3174-3219, 3631-3702).  The 5-diagonal systems the
  * reference solves with spsolve (src/prob1base.py:2103,2130) are solved by matrix-free Jacobi
  * sweeps: jacobi_sweeps[v] > 0 fixes the sweep count for v = T, cl, cd (from a zero iterate); <= 0 lets the
- * library choose it so that the last update is below jacobi_tol relative to the solution increment (capped at
- * jacobi_max): from the contraction bound of the system and, in a run of consecutive steps, from the
+ * library choose it so that the last update is below jacobi_tol relative to the solution increment, or below the
+ * floor relative to the unknown itself (option "jacobi_floor"), whichever is larger (capped at jacobi_max): from the contraction bound of the system and, in a run of consecutive steps, from the
  * convergence record of the step two before (the iteration then starts from the last step's increment).
  * Solves with a chosen count are judged afterwards (tedd_check_converged).  jacobi_sweeps may be NULL. */
 int tedd_step_pc(tedd_ctx* ctx, double t0, double dt, int32_t num_pc_steps, int32_t num_newton_steps,
@@ -250,8 +255,8 @@ int tedd_error_norms_noalloc(tedd_ctx* ctx, double t, double* out_device);
  * cs_iterations: Newton iterations the cs corrector kept (global early exit, src/prob1base.py:3661);
  * warm_started[v]: that solve started from the increment of the step before instead of zero, and
  * first_update[v] is the max-norm of its first sweep's update; worst_ratio[v]: the largest
- * last_update / (jacobi_tol x increment) over the steps since the last tedd_check_converged, counting only
- * solves whose sweep count the library chose. */
+ * last_update / max(jacobi_tol x increment, jacobi_floor x max|u|) over the steps since the last
+ * tedd_check_converged, counting only solves whose sweep count the library chose. */
 typedef struct tedd_step_stats {
     int32_t sweeps[3];
     int32_t cs_iterations;
@@ -266,7 +271,8 @@ int tedd_get_stats(tedd_ctx* ctx, tedd_step_stats* out);
 
 /* The reference solves its Newton systems directly (spsolve, src/prob1base.py:2103,2130), which cannot stop
  * short; Jacobi sweeps can.  Every solve whose sweep count the library chose is therefore judged on the
- * device after the fact (last update <= jacobi_tol x increment) and the worst ratio of all steps is kept.
+ * device after the fact (last update <= max(jacobi_tol x increment, jacobi_floor x max|u|)) and the worst ratio of
+ * all steps is kept.
  * tedd_check_converged returns TEDD_ERR_NOT_CONVERGED if some step since the last check missed its tolerance by
  * more than a factor 10, and clears the record.  tedd_advance performs this check before it returns; callers
  * that step with tedd_step_pc call it at their own synchronisation points (it synchronises the stream). */

@@ -45,6 +45,7 @@ def _run(N, nsteps, options, want_state, M=None, stretch=1.0):
         ctx.step_pc(t, dt)
         t += dt
     stats = ctx.get_stats()
+    ctx.check_converged()      # the library's own verdict on the sweep counts it chose
     norms = np.asarray(ctx.error_norms(t))
     out = {"stats": stats, "norms": norms, "t": t}
     if want_state:
@@ -88,6 +89,29 @@ def test_solver_variants_agree_4096():
             tol = 0.0 if name == "large tiles" else 1e-14 * max(s, 1.0)
             assert np.max(np.abs(a - b)) <= tol, name
         np.testing.assert_allclose(r["norms"], ref["norms"], rtol=1e-6, atol=1e-30, err_msg=name)
+
+
+def test_floor_of_the_stopping_rule_4096():
+    """On this mesh a step moves T by 8e-8 of its size, so jacobi_tol x increment asks for updates of 1e-20 in a
+    field whose rounding unit is 2e-16.  With the floor of the stopping rule (updates below 2^-62 max|u| count as
+    converged, option jacobi_floor) the warm-started T solve takes fewer sweeps than with the plain rule; the
+    library's verdict passes either way and the states differ by rounding only (the reference solves directly,
+    src/prob1base.py:2103, 2130: both runs are within 1e-15 of what it would give)."""
+    N, nsteps = 4096, 12
+    with_floor = _run(N, nsteps, {}, True)
+    plain = _run(N, nsteps, {"jacobi_floor": 0.0}, True)
+    sf, sp = with_floor["stats"], plain["stats"]
+    assert sf["warm_started"][0] == 1 and sp["warm_started"][0] == 1
+    assert sf["sweeps"][0] < sp["sweeps"][0], (sf["sweeps"], sp["sweeps"])
+    # the plain rule, met by the plain run and knowingly not by the other
+    assert sp["last_update"][0] <= 1e-12 * sp["increment"][0]
+    assert sf["last_update"][0] <= 10 * 2.0 ** -62 * 1.0          # max|T| <= 1 for this case
+    assert max(sf["worst_ratio"]) <= 10.0 and max(sp["worst_ratio"]) <= 10.0
+    for a, b in zip(with_floor["state"], plain["state"]):
+        assert np.max(np.abs(a - b)) <= 4.5e-16
+    # (the squared error norms are 1e-24 ... 1e-35 here, sums of squared rounding errors of the O(1) fields: the
+    # two runs agree in them as far as such sums can, to a few parts in a million)
+    np.testing.assert_allclose(with_floor["norms"], plain["norms"], rtol=1e-4, atol=1e-30)
 
 
 def test_bench_mesh_16384():
