@@ -44,12 +44,15 @@ NB_A = dict(R0=8.3144621, Ea=1.60217662e-19, K1=1e-3, K2=1e-3, K3=1e-3, K4=1e-3,
 
 # Distinct full-grid arrays read + written per launch of each kernel family (algorithmic traffic:
 # 8 bytes per node per array; stencil neighbours, tile halos and 1-D tables not counted).
-def arrays_per_launch(solver, cache_forcing, sweeps, hmax, fuse_forcing=1, warm=(False, False, False), fused_rhs=False):
+def arrays_per_launch(solver, cache_forcing, sweeps, hmax, fuse_forcing=1, warm=(False, False, False), fused_rhs=False,
+                      lazy_yt=False):
     """-> ({family: arrays per launch (chain families: average over the chain's launches)},
            {chain family: {"launches_per_solve", "arrays_per_solve"}})
     warm[k]: the solve of system k starts from the increment of the step before (its first launch also
     reads the unknown of the step before); fused_rhs: single-launch cl / cd solves evaluate their right-hand
-    side themselves (no rhs_cl / rhs_cd launch: the solve reads what that launch would have)."""
+    side themselves (no rhs_cl / rhs_cd launch: the solve reads what that launch would have); lazy_yt: the
+    predictor does not store Y_T (whole-mesh contexts with cached forcing and the register-resident solve: nothing
+    in the step reads it, tedd_get_residuals remakes it)."""
     a = {}
     if cache_forcing:
         a["forcing"] = 5        # writes fcp (cell averages), fT, fcl, fcd, fcs of the new time level
@@ -67,6 +70,8 @@ def arrays_per_launch(solver, cache_forcing, sweeps, hmax, fuse_forcing=1, warm=
     if solver == "strip":
         # + writes b = rhs/diag of the T system (no rhs_T launch), reading fT(t1) unless it is evaluated here
         a["predict"] += 1 + (f if not (cache_forcing and fuse_forcing) else 0)
+        if lazy_yt and cache_forcing:
+            a["predict"] -= 1
     w = 1 if solver == "strip" else 2           # strip: writes b = rhs/diag; others: rhs and delta_1
     a["rhs_T"] = 3 + f + w      # reads cp*, T, Y_T
     a["rhs_cl"] = 5 + f + w     # reads cp*, T, T_new, cl, Y_cl
@@ -484,7 +489,8 @@ def main():
     n_nodes_local = (slab.row_hi - slab.row_lo) * (N + 1)
     arrays, chains = arrays_per_launch(args.solver, args.cache_forcing, sweeps, args.hmax, args.fuse_forcing,
                                        warm=stats["warm_started"],
-                                       fused_rhs=args.solver == "strip" and "rhs_cl" not in prof)
+                                       fused_rhs=args.solver == "strip" and "rhs_cl" not in prof,
+                                       lazy_yt=args.solver == "strip" and world == 1)
 
     def gbps(fam):
         per_launch_s = prof[fam]["total_ms"] / prof[fam]["launches"] * 1e-3

@@ -139,6 +139,8 @@ public:
         int sweeps[3] = {0, 0, 0};
         int cs_iters_requested = 0;
         bool cs_newton_ran = false;
+        // Y_T was not stored (nothing in the step read it): what remakes it for the residuals
+        const double *lazy_T0 = nullptr, *lazy_cp0 = nullptr, *lazy_fT0 = nullptr;
     } last;
     bool stats_pending = false;
 
@@ -558,6 +560,17 @@ public:
         for (int v = 0; v < 3; ++v)
             if (prev[v] == p) return;
         if (std::find(free_bufs.begin(), free_bufs.end(), p) == free_bufs.end()) free_bufs.push_back(p);
+    }
+    // a buffer commit_state released (or that is still the warm start's) is held for tedd_get_residuals
+    void keep_until_next_step(double* p) {
+        if (!p) return;
+        for (int v = 0; v < 5; ++v)
+            if (cur[v] == p) return;
+        for (int v = 0; v < 3; ++v)
+            if (prev[v] == p) return;  // (kept anyway, until the next commit)
+        auto it = std::find(free_bufs.begin(), free_bufs.end(), p);
+        if (it != free_bufs.end()) free_bufs.erase(it);
+        if (std::find(retained.begin(), retained.end(), p) == retained.end()) retained.push_back(p);
     }
     void release_retained() {
         std::vector<double*> r;
@@ -1508,7 +1521,13 @@ public:
             fcp_time[k1] = t1;
         }
 
-        double* YT = B(Y0);
+        // Y_T is read by the right-hand side of the T system and by the Newton residual.  Where the predictor launch
+        // makes b_T itself and the step has one Newton step, nothing in the step reads Y_T: it is not stored, and
+        // remade from the old state if the residuals are asked for (whole-mesh contexts with library-owned forcing
+        // arrays, which stay in place until the next step).
+        const bool lazy_YT = Backend::kHasStripSolve && strip_now() && p.num_pc == 1 && p.num_newton == 1 && gl == 0 &&
+                             gr == 0 && forcing_from_cache && CASE == CASE_STREAM && mms_case != CASE_STREAM;
+        double* YT = lazy_YT ? nullptr : B(Y0);
         double* Ycl = B(Y0 + 1);
         double* Ycd = B(Y0 + 2);
         std::vector<double*> temps;  // everything acquired during this step
@@ -1590,7 +1609,8 @@ public:
                                          fcp_t1_out, dt, bT, ncp, ycs, Out5{}};
                 launch_split([&](int lo, int hi) { launch_predictor(f, lo, hi); });
             }
-            for (double* q : {YT, Ycl, Ycd, cpP, csP, ncp, ycs}) mark(q, r);
+            for (double* q : {YT, Ycl, Ycd, cpP, csP, ncp, ycs})
+                if (q) mark(q, r);
             if (bT) mark(bT, r);
             bT_ready = (bT != nullptr);
             if (fcp_t0_out) {
@@ -1663,8 +1683,20 @@ public:
         }
 
         double* nxt[5] = {cpU, To, clo, cdo, csU};
+        double* const old_cp = cur[VAR_CP];
+        double* const old_T = cur[VAR_T];
+        const double* const old_fT = f0.f[VAR_T];
         commit_state(nxt, true, dt);
         temp_guard.armed = false;
+        last.lazy_T0 = last.lazy_cp0 = last.lazy_fT0 = nullptr;
+        if (lazy_YT) {
+            // (the old cp and T stay out of the pool until the next step: commit_state has just handed them back)
+            keep_until_next_step(old_cp);
+            keep_until_next_step(old_T);
+            last.lazy_T0 = old_T;
+            last.lazy_cp0 = old_cp;
+            last.lazy_fT0 = old_fT;
+        }
         // keep what tedd_get_residuals needs; hand everything else back
         last.have = (cp_last_used != nullptr);
         last.t1 = t1;
@@ -1828,6 +1860,7 @@ public:
     struct ResOp {
         Ctx* c;
         double* out[3];
+        double* lazy_out;  // where Y_T is remade if the step did not store it
         template <int CASE, int REACT>
         void run() {
             Ctx& C = *c;
@@ -1842,6 +1875,14 @@ public:
             const double *cp = C.last.cp_used, *cs = C.last.cs_used;
             const double *T1 = C.cur[VAR_T], *cl1 = C.cur[VAR_CL], *cd1 = C.cur[VAR_CD];
             const double *YT = C.slot[Y0], *Ycl = C.slot[Y0 + 1], *Ycd = C.slot[Y0 + 2];
+            if (C.last.lazy_T0) {
+                // the step did not store Y_T: remake it from the old state (step_pc_impl)
+                const Range ry = C.need({{C.last.lazy_T0, true}, {C.last.lazy_cp0, false}, {C.last.lazy_fT0, false}});
+                LazyYTFn fy{g, C.model, C.last.lazy_T0, C.last.lazy_cp0, C.last.lazy_fT0, lazy_out, C.last.dt};
+                C.be.nodes(FAM_RESIDUAL, fy, ry.lo, ry.hi, C.ncols);
+                C.mark(lazy_out, ry);
+                YT = lazy_out;
+            }
             Range r = C.need({{cp, true}, {T1, true}, {cl1, true}, {cd1, true}, {cs, false}, {YT, false},
                               {Ycl, false}, {Ycd, false}});
             ResidualFn<VAR_T, CASE, REACT> a{g, C.model, C.tabs(), f1, cp, cs, T1, cl1, cd1, YT, out[0], C.last.dt};
@@ -1856,7 +1897,7 @@ public:
         if (!last.have) throw InvalidError("no predictor-corrector step has been taken since the state was set");
         Tmp5 tmp(this);
         for (int v = 0; v < 3; ++v) be.memset0(tmp.p[v], field_elems() * sizeof(double));
-        ResOp op{this, {tmp.p[0], tmp.p[1], tmp.p[2]}};
+        ResOp op{this, {tmp.p[0], tmp.p[1], tmp.p[2]}, tmp.p[3]};
         dispatch(op);
         for (int v = 0; v < 3; ++v)
             if (h[v]) download_field(h[v], op.out[v]);

@@ -287,7 +287,7 @@ struct PredictFn {
                         double cl0, double cd0, double cs0, double fcp1, double fcs1, double fT1) const {
         const double T0 = T.c;
         const double YTv = dt * F.T + 2.0 * T0;
-        put_once(YT + c, YTv);
+        if (YT) put_once(YT + c, YTv);  // (null: nothing of this step reads it; LazyYTFn makes it if the residuals are asked for)
         put_once(Ycl + c, dt * F.cl + 2.0 * cl0);
         put_once(Ycd + c, dt * F.cd + 2.0 * cd0);
         // Heun for cp (other fields frozen at t0)
@@ -691,6 +691,24 @@ struct JacobiFn {
     TEDD_HD void operator()(int li, int j) const {
         double red[2] = {0.0, 0.0};
         (*this)(li, j, red);
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// Y_T = dt F_T(S0, t0) + 2 T0 after the fact, by the operations of PredictFn: a step whose predictor launch also
+// made b_T, the only consumer of Y_T inside the step, does not store Y_T (one array pass of 68 fewer); the Newton
+// residual of T needs it, and is asked for rarely.
+struct LazyYTFn {
+    GridDev g;
+    ModelC m;
+    const double *T0, *cp0, *fT0;
+    double* out;
+    double dt;
+    TEDD_HD void operator()(int li, int j) const {
+        const size_t c = at(g, li, j);
+        double FT = fT0[c];
+        if (is_interior(g, li, j)) FT += rhs_T(m, geo_at(g, li, j), load5(T0, g, li, j), cp0[c]);
+        out[c] = dt * FT + 2.0 * T0[c];
     }
 };
 

@@ -401,6 +401,44 @@ def check_generated_kernels_equal_interpreter(react, which):
         c.close()
 
 
+def check_residuals_survive_other_calls():
+    """A step whose predictor launch makes b_T itself does not store Y_T (nothing in the step reads it);
+    tedd_get_residuals remakes it from the old cp and T, which stay out of the buffer pool until the next step.
+    Calls in between that take buffers from the pool (field evaluation, norms, forcing arrays) must not disturb
+    that: the residuals asked for twice are the same arrays, equal to those of the per-sweep solver (which stores
+    Y_T) to the rounding of the two solvers, and small (reference tests/test_newton_residuals.py:116-124)."""
+    N = 40
+    x = np.linspace(0, 1, N + 1) ** 1.1
+    y = np.linspace(0, 1, 34)
+    consts = [8.3144621, 1.60217662e-19, 1e-3, 1e-3, 1e-3, 1e-3, 1e-3, 1e-5, 1e-5, 1e-9, 1e-2, 1.0, 1e-6, 1e-5,
+              1.60217662e-19 / 8.3144621, 5e-2, 300.0]
+    out = {}
+    for name, opts in (("chain", {}), ("sweeps", {"strip_solve": 0})):
+        ctx = _ffi.Context(x, y, consts, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0,
+                           mms_case=_ffi.MMS_EXPSIN)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.set_state_exact(0.0)
+        dt = 1e-3
+        for k in range(3):
+            ctx.step_pc(k * dt, dt)
+        first = ctx.get_residuals()
+        ctx.eval_field(3 * dt)
+        ctx.error_norms(3 * dt)
+        ctx.eval_forcing(0.5)
+        ctx.eval_jacobian(5)
+        second = ctx.get_residuals()
+        for a, b in zip(first, second):
+            np.testing.assert_array_equal(a, b)
+        out[name] = first
+        ctx.step_pc(3 * dt, dt)            # ... and the next step finds its buffers
+        assert all(np.isfinite(a).all() for a in ctx.get_residuals())
+        ctx.close()
+    for a, b in zip(out["chain"], out["sweeps"]):
+        assert np.max(np.abs(a - b)) < 1e-14
+        assert np.max(np.abs(a[1:-1, 1:-1])) < 1e-9
+
+
 def check_skewed_header_tree_is_refused(tmp_dir):
     """The generated kernels are compiled at run time against the headers beside the library (or under
     $TEDD_CSRC_DIR) and take their argument structures by value from the prebuilt library.  A header tree that is not

@@ -17,6 +17,9 @@ def test_array_passes_of_the_default_step():
     assert sweeps == [20, 7, 5]
     arrays, chains = bench.arrays_per_launch("strip", 1, sweeps, 10, 0)
     assert arrays["predict"] == 21 and arrays["forcing"] == 5 and arrays["cs_newton"] == 8
+    # whole-mesh contexts do not store Y_T (nothing in the step reads it): one array fewer
+    lazy, _ = bench.arrays_per_launch("strip", 1, sweeps, 10, 0, lazy_yt=True)
+    assert lazy["predict"] == 20
     assert chains["solve_T"] == {"launches_per_solve": 2, "arrays_per_solve": 8}
     launches = {"forcing": 1, "predict": 1, "rhs_cl": 1, "rhs_cd": 1, "cs_newton": 1,
                 "solve_T": 2, "solve_cl": 1, "solve_cd": 1}

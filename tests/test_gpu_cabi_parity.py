@@ -155,6 +155,10 @@ def test_generated_program_kernels_equal_interpreter(react, which):
     cc.check_generated_kernels_equal_interpreter(react, which)
 
 
+def test_residuals_of_a_step_that_did_not_store_its_Y_T():
+    cc.check_residuals_survive_other_calls()
+
+
 def test_generated_kernels_refuse_a_header_tree_that_is_not_the_librarys(tmp_path):
     cc.check_skewed_header_tree_is_refused(tmp_path)
 
