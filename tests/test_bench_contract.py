@@ -75,7 +75,7 @@ def test_committed_pmc_summary_of_this_library_is_plausible():
     tr = bench.pmc_traffic("predict", cfg)
     if tr["bytes_per_launch"] is None:
         pytest.skip(tr["note"])
-    algorithmic = 8.0 * 16385 * 16385 * 21
+    algorithmic = 8.0 * 16385 * 16385 * 20      # 13 read, 7 written (Y_T is not stored on a whole-mesh context)
     assert algorithmic < tr["bytes_per_launch"] < 1.05 * algorithmic     # every array row is read once
     # (the right-hand sides march with their next row travelling into LDS: the two 16-byte granules a wave asks for
     # outside its own 64 columns are requests of their own, a few per cent of the launch's traffic)
