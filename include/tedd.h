@@ -152,7 +152,8 @@ int32_t tedd_pitch(const tedd_ctx* ctx);      /* device row pitch in doubles (>=
  * buffer sizes apart while that fits into half of the free device memory (the gaps stay unused), packed back to
  * back otherwise: launches that stream many arrays at once run up to 8 % slower with the buffers in consecutive
  * separate allocations.  TEDD_FIELD_GAP_MB in the environment sets the gap (MiB; 0 packed, -1 separate
- * allocations).  The string names the layout chosen, or why the buffers were allocated one by one. */
+ * allocations).  The string names the layout chosen, or why the buffers were allocated one by one; it belongs to the
+ * context and is valid until tedd_destroy. */
 const char* tedd_placement(const tedd_ctx* ctx);
 
 /* State (cp, T, cl, cd, cs): replaces StateVars' five arrays (src/prob1base.py:1959-2028). */

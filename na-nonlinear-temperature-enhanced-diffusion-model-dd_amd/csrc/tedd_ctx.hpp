@@ -621,7 +621,12 @@ public:
         for (int v = 0; v < 3; ++v) {
             double* p = prev[v];
             prev[v] = nullptr;
-            release(p);
+            if (p && last.have && p == last.lazy_T0) {
+                // (tedd_get_residuals may still remake Y_T from it: held until the next step instead)
+                if (std::find(retained.begin(), retained.end(), p) == retained.end()) retained.push_back(p);
+            } else {
+                release(p);
+            }
         }
         prev_dt = 0.0;
     }
@@ -1497,6 +1502,7 @@ public:
         const MmsTabs tb = tabs();
         const double t0 = p.t0, dt = p.dt, t1 = p.t0 + p.dt;
         const ForcingSrc f0 = forcing_src(t0, 0), f1 = forcing_src(t1, 1);
+        last.have = false;  // (what tedd_get_residuals needs of the step before goes back to the pool now)
         release_retained();
 
         // cp-forcing cell averages: reuse the array the last step computed for this time level

@@ -73,8 +73,11 @@ def _worker(rank, world, port, out_dir, options):
 # forcing_launch: the forcing arrays come from a launch of their own, enqueued by the slab stepper while the
 # ghost rows travel (the configuration of slabs too large for the predictor launch to make them)
 # overlap: the ghost rows of a step travel while the next step's predictor runs on the rows that do not need them
-@pytest.mark.parametrize("options", [{}, {"fuse_forcing": 0}, {"_overlap": True}, {"_overlap": True, "fuse_forcing": 0}],
-                         ids=["default", "forcing_launch", "overlap", "overlap-forcing_launch"])
+# march: the marching launchers that large slabs use, forced on this small mesh (the split predictor of the overlap mode
+# then runs its interior part in the marching launcher and its bands one thread per node)
+@pytest.mark.parametrize("options", [{}, {"fuse_forcing": 0}, {"_overlap": True}, {"_overlap": True, "fuse_forcing": 0},
+                                     {"_overlap": True, "fuse_forcing": 0, "march": 1}],
+                         ids=["default", "forcing_launch", "overlap", "overlap-forcing_launch", "overlap-marching"])
 def test_two_slabs_equal_single_slab(tmp_path, options):
     from tedd import _ffi
     _ffi.use_library(_ffi.DEFAULT_LIBRARY)
