@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Pin the reference-side binding (tedd/reference_stub.py, the listing of INTEGRATION.md) by RUNNING THE
+"""Pin the reference-side binding (tedd/reference_stub.py, the listing printed in the integration guide) by RUNNING THE
 REFERENCE with it.
 
 Run in the development container only (the reference never travels), after __graft_entry__.build():

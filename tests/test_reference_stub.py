@@ -180,7 +180,7 @@ def test_unconverged_solves_do_not_pass_silently():
 
 
 def test_listing_in_the_integration_notes_is_the_tested_file():
-    """INTEGRATION.md prints the binding; what it prints is the file these tests run."""
+    """The integration guide at the repository root prints the binding; what it prints is the file these tests run."""
     root = os.path.dirname(HERE)
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     src = open(reference_stub.__file__).read()
