@@ -11,6 +11,8 @@ sys.path.insert(0, os.path.join(ROOT, "na-nonlinear-temperature-enhanced-diffusi
 import bench  # noqa: E402
 from tedd import _ffi  # noqa: E402
 
+if os.environ.get("AB_LIBRARY"):  # (a probe build of the library, e.g. one whose predictor body is stripped)
+    _ffi.use_library(os.environ["AB_LIBRARY"])
 sets = [dict((kv.split("=")[0], float(kv.split("=")[1])) for kv in a.split(",") if kv) for a in sys.argv[1:]] or [{}]
 N = int(os.environ.get("AB_MESH", "16384"))
 x = np.linspace(0, 1, N + 1)
@@ -29,11 +31,18 @@ for rnd in range(3):
     for s in sets:
         for name, v in {**defaults, **s}.items():
             ctx.set_option(name, v)
-        ctx.step_pc(k * dt, dt)
+        def step():
+            try:
+                ctx.step_pc(k * dt, dt)
+            except Exception as e:  # (a probe library computes nonsense: the launches are timed all the same)
+                if not os.environ.get("AB_LIBRARY"):
+                    raise
+                print("step failed:", str(e)[:80], flush=True)
+        step()
         k += 1
         ctx.profile_enable(True)
         for _ in range(4):
-            ctx.step_pc(k * dt, dt)
+            step()
             k += 1
         ctx.sync()
         prof = ctx.profile_get()
