@@ -16,7 +16,9 @@ def main():
     want = sys.argv[1:]
     with tempfile.TemporaryDirectory() as d:
         fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "k.co")
-        subprocess.check_call([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, LIB])
+        # (with no output file llvm-objcopy rewrites its input in place, which changes the library's hash -- the
+        # identity the counter summaries under profiles/ are stamped with: the rewritten copy goes to the scratch directory)
+        subprocess.check_call([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, LIB, os.path.join(d, "copy.so")])
         subprocess.check_call([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
         notes = subprocess.run([LLVM + "/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
