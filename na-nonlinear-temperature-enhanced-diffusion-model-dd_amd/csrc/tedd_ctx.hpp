@@ -1926,12 +1926,15 @@ public:
         else if (name == "fuse_forcing")
             opt_fuse_forcing = value < 0.0 ? -1 : (value != 0.0);
         else if (name == "march" || name == "march_rows" || name == "march_occ" || name == "exact_faces" ||
-                 name == "forcing_columns" || name == "strip_panel" || name == "march_ahead" || name == "march_lds" || name == "cs_lean") {
+                 name == "forcing_columns" || name == "strip_panel" || name == "march_ahead" || name == "march_lds" || name == "cs_lean" ||
+                 name == "march_split") {
             if constexpr (Backend::kHasStripSolve) {
                 if (name == "exact_faces")
                     opt_exact_faces = value != 0.0;
                 else if (name == "march_ahead")
                     be.opt_march_ahead = value < 0.0 ? -1 : (value != 0.0);
+                else if (name == "march_split")
+                    be.opt_march_split = value < 0.0 ? -1 : (value != 0.0);
                 else if (name == "cs_lean")
                     be.opt_cs_lean = value != 0.0;
                 else if (name == "march_lds")

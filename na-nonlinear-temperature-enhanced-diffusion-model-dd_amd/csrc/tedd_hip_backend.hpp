@@ -443,6 +443,7 @@ struct HipBackend {
     int opt_cs_lean = 1;          // cs corrector of at most 5 iterations: the build with 5 records per thread, 5 waves per SIMD
     int opt_march_lds = -1;       // marching kernels without look-ahead in registers prefetch through LDS (-1: per functor)
     int opt_march_ahead = -1;     // marching kernels request the next row a row ahead (-1: per functor)
+    int opt_march_split = -1;     // look-ahead march: wait for the next row's loads between a node's arithmetic and its stores (0: the compiler's wait at the top of the row)
     int opt_strip_panel = 8;      // tile rows per panel of the strip launches' tile order (0: row-major)
     int opt_forcing_columns = 1;  // forcing arrays by column-walking threads (0: one thread per node)
     int opt_march_occ = 0;   // waves per SIMD the marching kernels' register budget is set for (0: per functor; 2, 3, 4)
@@ -1001,7 +1002,10 @@ struct HipBackend {
                     if (opt_march_lds != 0 && !ahead) {
                         // (two builds per functor: its own number of waves per SIMD and one fewer)
                         constexpr int K = F::kMarchOcc;
-                        if (occ < K)
+                        if (opt_march_split == 0)
+                            hipLaunchKernelGGL((k_march_lds<F, K, false>), dim3((unsigned)nt), dim3(64, kMarchWaves), 0, stream, f, r0, r1,
+                                               ncols, seg, tiles_x);
+                        else if (occ < K)
                             hipLaunchKernelGGL((k_march_lds<F, K - 1>), dim3((unsigned)nt), dim3(64, kMarchWaves), 0, stream, f, r0,
                                                r1, ncols, seg, tiles_x);
                         else
@@ -1012,8 +1016,12 @@ struct HipBackend {
                     }
                 }
                 auto go = [&](auto occ_c, auto ahead_c) {
-                    hipLaunchKernelGGL((k_march<F, decltype(occ_c)::value, decltype(ahead_c)::value>), dim3((unsigned)nt),
-                                       dim3(64, kMarchWaves), 0, stream, f, r0, r1, ncols, seg, tiles_x);
+                    if (opt_march_split == 0 && decltype(ahead_c)::value && HasNodeVals<F>::value)
+                        hipLaunchKernelGGL((k_march<F, decltype(occ_c)::value, decltype(ahead_c)::value, false>), dim3((unsigned)nt),
+                                           dim3(64, kMarchWaves), 0, stream, f, r0, r1, ncols, seg, tiles_x);
+                    else
+                        hipLaunchKernelGGL((k_march<F, decltype(occ_c)::value, decltype(ahead_c)::value>), dim3((unsigned)nt),
+                                           dim3(64, kMarchWaves), 0, stream, f, r0, r1, ncols, seg, tiles_x);
                 };
                 auto by_ahead = [&](auto occ_c) {
                     if (ahead)

@@ -23,6 +23,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "tedd_nodes.hpp"
 
 namespace tedd {
@@ -44,9 +46,21 @@ __device__ __forceinline__ double lane_above_or(double v, double edge) {
 
 constexpr int kMarchWaves = 4;  // waves side by side in a workgroup: 256 columns
 
+// A functor may give its node body in two parts -- NodeOut node_vals(...) and node_store(li, j, NodeOut) -- and the
+// look-ahead march then waits for the loads it has in flight between the two.  Why: the counter of outstanding vector
+// memory operations counts loads and stores alike, in order.  The compiler waits for the next row's loads where
+// their registers are first read, at the top of the next row, and because the row's stores sit behind branches it
+// cannot count them: it waits for everything, the stores it has just issued included, and a store's round trip
+// to memory joins every row's critical path.  With the wait placed before the stores the loads have had the whole
+// row's arithmetic to arrive, and the stores have the whole next row to complete.
+template <class F, class = void>
+struct HasNodeVals : std::false_type {};
+template <class F>
+struct HasNodeVals<F, std::void_t<typename F::NodeOut>> : std::true_type {};
+
 // OCC: waves per SIMD the register budget is set for.  AHEAD: request everything the next row needs before
 // the present row is computed (more registers; for kernels that run at two waves per SIMD).
-template <class F, int OCC, bool AHEAD>
+template <class F, int OCC, bool AHEAD, bool SPLIT = true>
 __global__ void __launch_bounds__(64 * kMarchWaves) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 k_march(const F f, int r0, int r1, int ncols, int seg_rows, int tiles_x) {
     constexpr int NS = F::NS, NC = F::NC;
@@ -96,6 +110,12 @@ k_march(const F f, int r0, int r1, int ncols, int seg_rows, int tiles_x) {
 #pragma unroll
         for (int k = 0; k < NC; ++k) cv[k] = cp[k] ? __builtin_nontemporal_load(cp[k] + oc + jc) : 0.0;
     }
+    if constexpr (AHEAD && SPLIT && HasNodeVals<F>::value) {
+        // the first rows are waited for here, once: a wait at the top of the loop that has to serve the first entry
+        // would also be executed on every later one, where all it could wait for is the row's stores
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
+    }
     for (int li = ra; li < rb; ++li) {
         // AHEAD: everything the NEXT row needs is requested before this row is computed: row li+2 of the
         // stencil arrays, the edge values and the node-only arrays of row li+1 (clamped past the end of the
@@ -128,9 +148,21 @@ k_march(const F f, int r0, int r1, int ncols, int seg_rows, int tiles_x) {
             s[k].n = lane_above_or(c[k], edge[k]);
             s[k].s = lane_below_or(c[k], edge[k]);
         }
+        // Row metrics: one address per wave, written before the launch and never during it, read through the
+        // constant address space (scalar loads).  As vector loads they would be the youngest loads of the row, and
+        // the wait for them in the middle of the row's arithmetic would be a wait for the whole look-ahead batch.
         const int lic = min(li, rmax);
-        const Geo ge{g.rh[lic], g.rh[min(lic + 1, rmax)], g.rhm[lic], rks, rkn, rkm};
-        if (col_ok) f.node(li, j, ge, s, cv);
+        const Geo ge{tab_row_entry(g.rh, lic), tab_row_entry(g.rh, min(lic + 1, rmax)), tab_row_entry(g.rhm, lic), rks, rkn, rkm};
+        if constexpr (AHEAD && SPLIT && HasNodeVals<F>::value) {
+            typename F::NodeOut o{};
+            if (col_ok) o = f.node_vals(li, j, ge, s, cv);
+            // (vmcnt 0, expcnt and lgkmcnt left alone; the builtin, so that the compiler's own bookkeeping sees it)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            asm volatile("" ::: "memory");
+            if (col_ok) f.node_store(li, j, o);
+        } else {
+            if (col_ok) f.node(li, j, ge, s, cv);
+        }
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             w[k] = c[k];
@@ -164,7 +196,7 @@ k_march(const F f, int r0, int r1, int ncols, int seg_rows, int tiles_x) {
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* global_void_ptr;
 
-template <class F, int OCC>
+template <class F, int OCC, bool SPLIT = true>
 __global__ void __launch_bounds__(64 * kMarchWaves) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 k_march_lds(const F f, int r0, int r1, int ncols, int seg_rows, int tiles_x) {
     constexpr int NS = F::NS, NC = F::NC;
@@ -236,16 +268,22 @@ k_march_lds(const F f, int r0, int r1, int ncols, int seg_rows, int tiles_x) {
     // that row: vector loads complete in order, so the wait for these never waits for the batch behind them.
     double m_rh0 = g.rh[min(ra, rmax)], m_rh1 = g.rh[min(min(ra, rmax) + 1, rmax)], m_rhm = g.rhm[min(ra, rmax)];
     request(0, ra);
+    if constexpr (SPLIT && HasNodeVals<F>::value) {  // (the first batch and the first rows: waited for once, here)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
+    }
     for (int li = ra; li < rb; ++li) {
         const int slot = (li - ra) & 1;
         {
             const double* base = &ring[wave][slot][0];
             // The batch asked for a row ago has arrived once every vector memory operation of the wave has (they
-            // complete in order; the only younger ones are the stores of the row before).  The compiler does not
-            // connect the reads below with the loads that wrote LDS: the wait is spelled out.
+            // complete in order).  The compiler does not connect the reads below with the loads that wrote LDS: the
+            // wait is spelled out.  Where it stands: a functor in two parts (HasNodeVals) is waited for at the end of
+            // the row before, between its arithmetic and its stores -- the batch has had that row's arithmetic to
+            // arrive and the stores have this row's to complete; otherwise here, behind the stores of the row before.
             // (the builtin, not an asm string: the compiler's own bookkeeping of outstanding loads sees it.  gfx9
             // encoding: vmcnt 0, expcnt and lgkmcnt left alone)
-            __builtin_amdgcn_s_waitcnt(0x0F70);
+            if constexpr (!(SPLIT && HasNodeVals<F>::value)) __builtin_amdgcn_s_waitcnt(0x0F70);
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
@@ -271,7 +309,15 @@ k_march_lds(const F f, int r0, int r1, int ncols, int seg_rows, int tiles_x) {
             s[k].s = lane_below_or(c[k], edge[k]);
         }
         const Geo ge{m_rh0, m_rh1, m_rhm, rks, rkn, rkm};  // = rh[lic], rh[min(lic + 1, rmax)], rhm[lic], lic = min(li, rmax)
-        if (col_ok) f.node(li, j, ge, s, cv);
+        if constexpr (SPLIT && HasNodeVals<F>::value) {
+            typename F::NodeOut o{};
+            if (col_ok) o = f.node_vals(li, j, ge, s, cv);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            asm volatile("" ::: "memory");
+            if (col_ok) f.node_store(li, j, o);
+        } else {
+            if (col_ok) f.node(li, j, ge, s, cv);
+        }
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             w[k] = c[k];

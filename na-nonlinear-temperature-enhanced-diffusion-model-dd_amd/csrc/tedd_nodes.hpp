@@ -283,25 +283,29 @@ struct PredictFn {
     }
     // Everything after the field evaluation: Y, the Heun predictors, b_T and the corrector parts.
     // T: lagged T at the node and (where b_T is wanted, interior nodes) its four neighbours.
-    TEDD_HD void finish(size_t c, bool in, const Geo& ge, const F5& F, const Forcing5& fa, double cp0, const St5& T,
-                        double cl0, double cd0, double cs0, double fcp1, double fcs1, double fT1) const {
+    // The values first, the stores after them: a launcher that has the next row's loads in flight can wait for
+    // them between the two (NodeOut, node_vals, node_store below).
+    struct Out {
+        double YT, Ycl, Ycd, cp1, bT, cs1, ncp, ycs;
+    };
+    TEDD_HD Out finish_vals(bool in, const Geo& ge, const F5& F, const Forcing5& fa, double cp0, const St5& T, double cl0,
+                            double cd0, double cs0, double fcp1, double fcs1, double fT1) const {
+        Out o;
         const double T0 = T.c;
-        const double YTv = dt * F.T + 2.0 * T0;
-        if (YT) put_once(YT + c, YTv);  // (null: nothing of this step reads it; LazyYTFn makes it if the residuals are asked for)
-        put_once(Ycl + c, dt * F.cl + 2.0 * cl0);
-        put_once(Ycd + c, dt * F.cd + 2.0 * cd0);
+        o.YT = dt * F.T + 2.0 * T0;
+        o.Ycl = dt * F.cl + 2.0 * cl0;
+        o.Ycd = dt * F.cd + 2.0 * cd0;
         // Heun for cp (other fields frozen at t0)
         const double cps = cp0 + dt * F.cp;
         const double Fcps = fcp1 + (in ? rhs_cp(m, cps, T0, cl0) : 0.0);
         const double cp1v = cp0 + 0.5 * dt * (F.cp + Fcps);
-        put_once(cp1 + c, cp1v);
+        o.cp1 = cp1v;
+        o.bT = 0.0;
         if (bT) {  // same arithmetic as newton_rhs_value<VAR_T> / newton_row<VAR_T>
-            double bv = 0.0;
             if (in) {
-                const double r = YTv - (2.0 * T.c - dt * (fT1 + rhs_T(m, ge, T, cp1v)));
-                bv = tedd_div(r, 2.0 - dt * jac_T_FT(m, ge, cp1v).c);
+                const double r = o.YT - (2.0 * T.c - dt * (fT1 + rhs_T(m, ge, T, cp1v)));
+                o.bT = tedd_div(r, 2.0 - dt * jac_T_FT(m, ge, cp1v).c);
             }
-            put_once(bT + c, bv);
         }
         // Heun for cs
         double v;
@@ -311,19 +315,34 @@ struct PredictFn {
             const double Fcss = in ? (fcs1 - reaction<REACT>(m, cl0, cd0, css)) : 0.0;
             v = cs0 + (0.5 * dt) * (F.cs + Fcss);
         }
-        put_once(cs1 + c, (REACT != REACT_CS3) ? (in ? v : 0.0 * v) : v);  // RegHCs/HCs: times the interior mask (:3645, :3374)
+        o.cs1 = (REACT != REACT_CS3) ? (in ? v : 0.0 * v) : v;  // RegHCs/HCs: times the interior mask (:3645, :3374)
         // corrector inputs
         const double h = dt / 2;
         const double al0 = -m.K2 * T0 - m.K1 * (cl0 + 1.0);
-        put_once(ncp + c, in ? (1.0 + h * al0) * cp0 + h * (fa.fcp + fcp1) : 0.0);
+        o.ncp = in ? (1.0 + h * al0) * cp0 + h * (fa.fcp + fcp1) : 0.0;
         if (REACT == REACT_REG) {
-            put_once(ycs + c, 2.0 * cs0 - dt * m.Kd * (m.Sd - cd0) * (cl0 + 1.0) * heaviside_reg(cs0, m.eta) + dt * (fa.fcs + fcs1));
+            o.ycs = 2.0 * cs0 - dt * m.Kd * (m.Sd - cd0) * (cl0 + 1.0) * heaviside_reg(cs0, m.eta) + dt * (fa.fcs + fcs1);
         } else if (REACT == REACT_HCS) {
-            put_once(ycs + c, 2.0 * cs0 + dt * F.cs + dt * fcs1);  // Y0 of the sign-case corrector (:3412)
+            o.ycs = 2.0 * cs0 + dt * F.cs + dt * fcs1;  // Y0 of the sign-case corrector (:3412)
         } else {
             const double b0 = -m.Kd * (m.Sd - cd0) * (1.0 + cl0);
-            put_once(ycs + c, in ? (1.0 + h * b0) * cs0 + h * (fa.fcs + fcs1) : 0.0);
+            o.ycs = in ? (1.0 + h * b0) * cs0 + h * (fa.fcs + fcs1) : 0.0;
         }
+        return o;
+    }
+    TEDD_HD void finish_store(size_t c, const Out& o) const {
+        if (YT) put_once(YT + c, o.YT);  // (null: nothing of this step reads it; LazyYTFn makes it if the residuals are asked for)
+        put_once(Ycl + c, o.Ycl);
+        put_once(Ycd + c, o.Ycd);
+        put_once(cp1 + c, o.cp1);
+        if (bT) put_once(bT + c, o.bT);
+        put_once(cs1 + c, o.cs1);
+        put_once(ncp + c, o.ncp);
+        put_once(ycs + c, o.ycs);
+    }
+    TEDD_HD void finish(size_t c, bool in, const Geo& ge, const F5& F, const Forcing5& fa, double cp0, const St5& T,
+                        double cl0, double cd0, double cs0, double fcp1, double fcs1, double fT1) const {
+        finish_store(c, finish_vals(in, ge, F, fa, cp0, T, cl0, cd0, cs0, fcp1, fcs1, fT1));
     }
 
     // ---- interface of the marching launcher (tedd_march.hpp), array-fed forcing only: the arrays a node
@@ -347,11 +366,18 @@ struct PredictFn {
         return k == 0 ? S.v[VAR_CS] : k <= 5 ? f0.f[k - 1] : k == 6 ? f1.f[0] : k == 7 ? f1.f[4] : (bT ? f1.f[1] : nullptr);
     }
     TEDD_HD void node(int li, int j, const Geo& ge, const St5* s, const double* cv) const {
+        node_store(li, j, node_vals(li, j, ge, s, cv));
+    }
+    // the same in two parts: everything the node computes, then its stores (the launcher waits for the loads it has
+    // in flight in between, so that no wait of a later row ever has the stores of this one ahead of it)
+    typedef Out NodeOut;
+    TEDD_HD Out node_vals(int li, int j, const Geo& ge, const St5* s, const double* cv) const {
         const bool in = is_interior(g, li, j);
         const Forcing5 fa{cv[1], cv[2], cv[3], cv[4], cv[5]};
         const F5 F = node_field_vals<REACT>(m, ge, s[0], s[1], s[2], s[3], cv[0], fa, in);
-        finish(at(g, li, j), in, ge, F, fa, s[0].c, s[1], s[2].c, s[3].c, cv[0], cv[6], cv[7], cv[8]);
+        return finish_vals(in, ge, F, fa, s[0].c, s[1], s[2].c, s[3].c, cv[0], cv[6], cv[7], cv[8]);
     }
+    TEDD_HD void node_store(int li, int j, const Out& o) const { finish_store(at(g, li, j), o); }
 };
 
 // ------------------------------------------------------------------------------------
@@ -536,12 +562,19 @@ struct NewtonRhsFn {
         return k == 0 ? a.Ycd : k == 1 ? f1.f[VAR_CD] : k == 2 ? a.clo : k == 3 ? a.cs1 : a.cln;
     }
     TEDD_HD void node(int li, int j, const Geo& ge, const St5* s, const double* cv) const {
+        node_store(li, j, node_vals(li, j, ge, s, cv));
+    }
+    // the same in two parts (see HasNodeVals in tedd_march.hpp): right-hand side and first iterate, then their stores
+    struct NodeOut {
+        double r, d;
+    };
+    TEDD_HD void node_store(int li, int j, const NodeOut& o) const {
         const size_t c = at(g, li, j);
-        if (!is_interior(g, li, j)) {
-            if (rhs) rhs[c] = 0.0;
-            d1[c] = 0.0;
-            return;
-        }
+        if (rhs) rhs[c] = o.r;  // not needed by solvers that iterate on rhs/diag
+        d1[c] = o.d;
+    }
+    TEDD_HD NodeOut node_vals(int li, int j, const Geo& ge, const St5* s, const double* cv) const {
+        if (!is_interior(g, li, j)) return NodeOut{0.0, 0.0};
         const int i = g.i0 + li;
         const double w_ok = (i > 1) ? 1.0 : 0.0, e_ok = (i < g.N - 1) ? 1.0 : 0.0;
         Face4 D;
@@ -551,8 +584,7 @@ struct NewtonRhsFn {
                                                      clnc, &D);
         double diag, oe, ow, on, os;
         newton_row_vals<VAR, REACT>(m, ge, dt, s[0].c, s[1].e, s[1].w, D, clc, csc, diag, oe, ow, on, os);
-        if (rhs) rhs[c] = r;
-        d1[c] = tedd_div(r, diag);
+        return NodeOut{r, tedd_div(r, diag)};
     }
 };
 

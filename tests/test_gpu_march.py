@@ -45,7 +45,9 @@ def _run(N, M, react, options, row_lo=0, row_hi=None, ghost=0):
 def test_marching_launcher_is_bit_identical(N, M, react):
     ref = _run(N, M, react, {"march": 0})
     for opts in ({"march": 1}, {"march": 1, "march_occ": 2, "march_rows": 8}, {"march": 1, "march_occ": 3, "march_rows": 16},
-                 {"march": 1, "march_occ": 4, "march_rows": 5}):
+                 {"march": 1, "march_occ": 4, "march_rows": 5},
+                 # the wait for the next row's loads left to the compiler instead of placed before the row's stores
+                 {"march": 1, "march_split": 0}, {"march": 1, "march_occ": 2, "march_rows": 8, "march_split": 0}):
         got = _run(N, M, react, opts)
         for a, b in zip(ref, got):
             np.testing.assert_array_equal(a, b, err_msg=str(opts))
