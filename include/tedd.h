@@ -115,7 +115,10 @@ int tedd_set_mms_program(tedd_ctx* ctx, int32_t which, const uint32_t* code, int
  * every array row is read once) instead of one thread per node -- bit-identical results; "march_rows",
  * "march_occ": rows per segment and waves per SIMD of that launcher (0: the kernel's own choice); "march_lds"
  * (default -1: the right-hand sides; 0 never): a marching launch without look-ahead in registers has the next
- * row written into LDS by the load unit while it computes the present one -- bit-identical results; "cs_lean"
+ * row written into LDS by the load unit while it computes the present one -- bit-identical results;
+ * "march_split" (default -1 = 1): the marching launches wait for the next row's loads between a node's arithmetic
+ * and its stores (0: where the compiler puts the wait, at the top of the next row behind the stores: the launches of
+ * before, kept for comparison) -- bit-identical results; "cs_lean"
  * (default 1): RegHCsTriple corrector launches of at most 5 Newton iterations use a build that keeps 5 instead of
  * 8 per-iteration records per thread and runs 5 instead of 4 waves per SIMD -- same arithmetic;
  * "forcing_columns" (default 1): the forcing arrays of a closed-form case are made by threads that walk down

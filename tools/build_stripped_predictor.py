@@ -1,6 +1,6 @@
 """Build a PROBE copy of the library whose marching predictor body does no arithmetic: PredictFn::node sums the values
 the launcher hands it and stores the sums, so the launch keeps its loads, stores, arrays, segments and grid and loses
-its 560 vector instructions per node.  Timed beside the real library inside one context
+its 570 vector instructions per node.  Timed beside the real library inside one context
 (AB_LIBRARY=tools/bin/libtedd_stripped_predictor.so python tools/ab_options.py march_occ=0) it gives the memory floor of
 the predictor launch where its buffers really lie.  The copy computes nonsense: only its `predict` time means anything.
 The sources are patched in a temporary directory; nothing under the package changes."""
@@ -14,31 +14,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "na-nonlinear-temperature-enhanced-diffusion-model-dd_amd")
 OUT = os.path.join(ROOT, "tools", "bin", "libtedd_stripped_predictor.so")
 
-ANCHOR = """    TEDD_HD void node(int li, int j, const Geo& ge, const St5* s, const double* cv) const {
+ANCHOR = """    TEDD_HD Out node_vals(int li, int j, const Geo& ge, const St5* s, const double* cv) const {
         const bool in = is_interior(g, li, j);
-        const Forcing5 fa{cv[1], cv[2], cv[3], cv[4], cv[5]};
-        const F5 F = node_field_vals<REACT>(m, ge, s[0], s[1], s[2], s[3], cv[0], fa, in);
-        finish("""
-STRIPPED = """    TEDD_HD void node(int li, int j, const Geo& ge, const St5* s, const double* cv) const {
+"""
+STRIPPED = """    TEDD_HD Out node_vals(int li, int j, const Geo& ge, const St5* s, const double* cv) const {
         {
-            const size_t c = at(g, li, j);
             double a = ge.rhw + ge.rks;
             for (int k = 0; k < 4; ++k) a += (s[k].c + s[k].e) + (s[k].w + s[k].n) + s[k].s;
             for (int k = 0; k < 9; ++k) a += cv[k];
-            if (YT) put_once(YT + c, a);
-            put_once(Ycl + c, a + 1.0);
-            put_once(Ycd + c, a + 2.0);
-            put_once(cp1 + c, a + 3.0);
-            if (bT) put_once(bT + c, a + 4.0);
-            put_once(cs1 + c, a + 5.0);
-            put_once(ncp + c, a + 6.0);
-            put_once(ycs + c, a + 7.0);
-            return;
+            return Out{a, a + 1.0, a + 2.0, a + 3.0, a + 4.0, a + 5.0, a + 6.0, a + 7.0};
         }
         const bool in = is_interior(g, li, j);
-        const Forcing5 fa{cv[1], cv[2], cv[3], cv[4], cv[5]};
-        const F5 F = node_field_vals<REACT>(m, ge, s[0], s[1], s[2], s[3], cv[0], fa, in);
-        finish("""
+"""
 
 
 def main():
