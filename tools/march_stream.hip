@@ -9,7 +9,7 @@
 #include <cstdlib>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-template <int NR, int NW, int D>
+template <int NR, int NW, int D, bool SPLIT = false>
 __global__ void __launch_bounds__(256) k_march_stream(const double* base, size_t array_step, size_t ld, int nrows, int ncols,
                                                       int seg_rows, int tiles_x, int work) {
     extern __shared__ double pad[];
@@ -30,6 +30,10 @@ __global__ void __launch_bounds__(256) k_march_stream(const double* base, size_t
 #pragma unroll
         for (int k = 0; k < NR; ++k)
             ring[d][k] = __builtin_nontemporal_load(base + k * array_step + (size_t)min(ra + d, nrows - 1) * ld + j);
+    if (SPLIT) {  // (the library's placement of the waits: once before the loop, then between arithmetic and stores)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
+    }
     for (int li = ra; li < rb; ++li) {
         double cur[NR], nxt[NR];
 #pragma unroll
@@ -52,6 +56,10 @@ __global__ void __launch_bounds__(256) k_march_stream(const double* base, size_t
             s3 = __builtin_fma(s3, 0.9999998, 0.0625);
         }
         const double s = (s0 + s1) + (s2 + s3);
+        if (SPLIT) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            asm volatile("" ::: "memory");
+        }
         if (col_ok) {
             const size_t oc = (size_t)li * ld + j;
 #pragma unroll
@@ -66,11 +74,11 @@ __global__ void __launch_bounds__(256) k_march_stream(const double* base, size_t
     }
 }
 
-template <int NR, int NW, int D>
+template <int NR, int NW, int D, bool SPLIT = false>
 double run(const double* base, size_t array_step, size_t ld, int n, int seg_rows, int wg_per_cu, int work, int reps) {
     const int tiles_x = (n + 255) / 256, tiles_y = (n - 1 + seg_rows - 1) / seg_rows;
     const int lds = wg_per_cu >= 8 ? 0 : (160 * 1024 / wg_per_cu) / 1024 * 1024 - 1024;
-    auto kern = k_march_stream<NR, NW, D>;
+    auto kern = k_march_stream<NR, NW, D, SPLIT>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     dim3 block(64, 4), grid(tiles_x * tiles_y);
     hipEvent_t a, b;
@@ -113,15 +121,21 @@ int main(int argc, char** argv) {
     if (argc > 2) {  // the ceiling of every read/write mix of the step's launches: no arithmetic, best of the occupancies
         auto best = [&](auto fn) { double b = 0; for (int wg : {2, 3, 4, 6, 8}) { const double v = fn(wg); b = v > b ? v : b; } return b; };
         const size_t st = 2 * S2M / 8;
-        printf("marching streams without arithmetic, 32-row segments, one row ahead, best of 2..8 workgroups per CU (GB/s)\n");
-        printf("  13 R + 7 W (predictor):   %5.0f\n", best([&](int wg) { return run<13, 7, 1>(base, st, ld, n, 32, wg, 0, 4); }));
-        printf("   6 R + 1 W (rhs_cl):      %5.0f\n", best([&](int wg) { return run<6, 1, 1>(base, st, ld, n, 32, wg, 0, 4); }));
-        printf("   9 R + 1 W (rhs_cd):      %5.0f\n", best([&](int wg) { return run<9, 1, 1>(base, st, ld, n, 32, wg, 0, 4); }));
-        printf("   6 R + 2 W (cs corrector):%5.0f\n", best([&](int wg) { return run<6, 2, 1>(base, st, ld, n, 32, wg, 0, 4); }));
-        printf("   4 R + 1 W (T, cl solve): %5.0f\n", best([&](int wg) { return run<4, 1, 1>(base, st, ld, n, 32, wg, 0, 4); }));
-        printf("   6 R + 1 W (cd solve):    %5.0f\n", best([&](int wg) { return run<6, 1, 1>(base, st, ld, n, 32, wg, 0, 4); }));
-        printf("   1 R + 5 W (forcing + 1): %5.0f\n", best([&](int wg) { return run<1, 5, 1>(base, st, ld, n, 32, wg, 0, 4); }));
-        printf("   1 R + 1 W (copy):        %5.0f\n", best([&](int wg) { return run<1, 1, 1>(base, st, ld, n, 32, wg, 0, 4); }));
+        printf("marching streams without arithmetic, 32-row segments, one row ahead, best of 2..8 workgroups per CU (GB/s):\n");
+        printf("the compiler's waits | the wait placed between the row's sum and its stores\n");
+#define MIX(NR_, NW_, what) printf("  %2d R + %d W (%s): %5.0f | %5.0f\n", NR_, NW_, what, \
+        best([&](int wg) { return run<NR_, NW_, 1, false>(base, st, ld, n, 32, wg, 0, 4); }), \
+        best([&](int wg) { return run<NR_, NW_, 1, true>(base, st, ld, n, 32, wg, 0, 4); }))
+        MIX(13, 7, "predictor");
+        MIX(6, 1, "rhs_cl");
+        MIX(9, 1, "rhs_cd");
+        MIX(6, 2, "cs corrector");
+        MIX(4, 1, "T, cl solve");
+        MIX(6, 1, "cd solve");
+        MIX(1, 5, "forcing + 1");
+        MIX(1, 1, "copy");
+        printf("with 564 instructions of dependent-chain work a row, 13 R + 7 W, by workgroups per CU:\n");
+        for (int wg : {2, 3, 4}) printf("  wg/CU %d: %5.0f | %5.0f\n", wg, run<13, 7, 1, false>(base, st, ld, n, 32, wg, 564, 4), run<13, 7, 1, true>(base, st, ld, n, 32, wg, 564, 4));
         return 0;
     }
     table<13, 7>("predictor", base, 2 * S2M / 8, ld, n);
