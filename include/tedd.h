@@ -99,7 +99,7 @@ int tedd_set_mms_program(tedd_ctx* ctx, int32_t which, const uint32_t* code, int
  * the same results).  "strip_solve" (default 1): solve the Newton systems with the register-resident
  * kernel chain (several Jacobi sweeps per launch) instead of one launch per sweep; "strip_hmax": sweeps
  * per launch (0 = automatic, at most 16); "strip_shape" (default -1: by mesh size and system; 0: 64-row tiles
- * of 4 strips, 1: 32-row tiles of 8 short strips for meshes too small to fill the GPU, 2: 48-row tiles of 12
+ * of 4 strips, 4: 64-row tiles of 8 strips for the T system (cl, cd: as -1), 1: 32-row tiles of 8 short strips for meshes too small to fill the GPU, 2: 48-row tiles of 12
  * short strips, 3: 16-row tiles of 8 strips of two rows for the cl and cd systems (T: as 1) on meshes with fewer
  * small tiles than compute units); "cache_forcing" (default 1): evaluate the closed-form MMS
  * forcing once per time level into arrays instead of inside the step kernels; "fuse_forcing" (default -1:

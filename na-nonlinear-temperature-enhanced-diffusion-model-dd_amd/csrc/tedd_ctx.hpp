@@ -1284,7 +1284,7 @@ public:
     // options
     int opt_strip = 1;      // 1: register-resident solve chain (backends that have it); 0: one launch per sweep
     int opt_strip_hmax = 0;         // sweeps fused per launch (0 = automatic)
-    int opt_strip_shape = -1;       // tile shape of the chain: -1 by mesh size and system, 0: 64 rows, 1: 32 rows, 2: 48 rows
+    int opt_strip_shape = -1;       // tile shape of the chain: -1 by mesh size and system, 0: 64 rows (4 waves x 16), 1: 32 rows, 2: 48 rows, 3: 16 rows (cl, cd), 4: 64 rows (8 waves x 8, T)
     // single-launch cl / cd chains evaluate their right-hand side themselves: -1 on slabs of at most 4 M nodes
     // (a launch and five to seven array passes fewer per solve; on large slabs the arithmetic repeated in the
     // tile halos costs more than the passes: 16384^2, rhs + solve launches 6.75 / 8.66 ms against 6.79 / 9.47 fused)

@@ -1228,10 +1228,10 @@ struct HipBackend {
         TEDD_HIP(hipGetLastError());
     }
     // one launch of the register-resident Newton solve chain (tedd_strip.hpp)
-    // shape: SHAPE_LARGE / SHAPE_SMALL / SHAPE_MID, or -1 = by mesh size and system: small tiles when
+    // shape: one of the SHAPE_* of tedd_strip.hpp, or -1 = by mesh size and system: small tiles when
     // the large ones would leave most compute units without work (fewer than half a tile per unit); otherwise
-    // large tiles for T and 48-row tiles for cl and cd (tedd_strip.hpp, StripShape).  A shape whose
-    // tile the depth H does not fit falls back to the large one.
+    // 64-row tiles of 8 waves x 8 rows for T and 48-row tiles for cl and cd (tedd_strip.hpp, StripShape).  A shape
+    // whose tile the depth H does not fit falls back to the large one.
     // tile shape of a strip launch of depth H over rows [r0, r1): the caller's choice, or by mesh size and system
     int strip_shape_for(int var, int H, int r0, int r1, int ncols, int shape) const {
         const int TIC = kSTile - 2 * strip_col_halo(H);
@@ -1241,6 +1241,7 @@ struct HipBackend {
             return tiles_x * ((r1 - r0 + TIR - 1) / TIR);
         };
         auto fits = [&](int sh) { return strip_tile_rows(sh) - 2 * H >= (sh == SHAPE_TINY ? 6 : 8); };
+        if (shape == SHAPE_OCT && var != VAR_T) shape = -1;  // (built for the T system only)
         if (shape < 0) {
             // (half a tile per compute unit is where the small tiles stop paying: alternated inside one context,
             // per step with small tiles / with the shapes of large meshes: 512^2 0.11 / 0.11 ms, 640^2 0.16 / 0.14,
@@ -1251,7 +1252,7 @@ struct HipBackend {
                 // ... and compute units to spare: two rows per thread (cl, cd)
                 if (var != VAR_T && fits(SHAPE_TINY) && n_tiles(SHAPE_TINY) <= num_cus) shape = SHAPE_TINY;
             } else {
-                shape = (var != VAR_T && H <= 8) ? SHAPE_MID : SHAPE_LARGE;
+                shape = (var == VAR_T) ? SHAPE_OCT : (H <= 8) ? SHAPE_MID : SHAPE_LARGE;
             }
         }
         if (shape == SHAPE_TINY && (var == VAR_T || !fits(SHAPE_TINY))) shape = SHAPE_SMALL;  // (built for cl and cd only)
@@ -1265,10 +1266,10 @@ struct HipBackend {
         return strip_shape_for(var, H, r0, r1, ncols, shape) != SHAPE_LARGE;
     }
     // one launch of the register-resident Newton solve chain (tedd_strip.hpp)
-    // shape: SHAPE_LARGE / SHAPE_SMALL / SHAPE_MID, or -1 = by mesh size and system: small tiles when
+    // shape: one of the SHAPE_* of tedd_strip.hpp, or -1 = by mesh size and system: small tiles when
     // the large ones would leave most compute units without work (fewer than half a tile per unit); otherwise
-    // large tiles for T and 48-row tiles for cl and cd (tedd_strip.hpp, StripShape).  A shape whose
-    // tile the depth H does not fit falls back to the large one.
+    // 64-row tiles of 8 waves x 8 rows for T and 48-row tiles for cl and cd (tedd_strip.hpp, StripShape).  A shape
+    // whose tile the depth H does not fit falls back to the large one.
     template <int VAR, int REACT, bool LAST>
     void solve_strip(int fam, StripArgs A, int ncols, int shape = -1) {
         if (A.r1 <= A.r0) return;
@@ -1341,6 +1342,8 @@ struct HipBackend {
             by_fused(std::integral_constant<int, (VAR == VAR_T) ? SHAPE_SMALL : SHAPE_TINY>{});
         else if (shape == SHAPE_MID)
             by_fused(std::integral_constant<int, SHAPE_MID>{});
+        else if (shape == SHAPE_OCT)
+            by_fused(std::integral_constant<int, (VAR == VAR_T) ? SHAPE_OCT : SHAPE_LARGE>{});
         else
             by_fused(std::integral_constant<int, SHAPE_LARGE>{});
         TEDD_HIP(hipGetLastError());

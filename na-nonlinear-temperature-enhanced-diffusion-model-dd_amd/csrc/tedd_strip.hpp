@@ -52,12 +52,18 @@ constexpr int kSTile = 64;  // tile width (nodes = lanes), halo included
 //   (256^2, in-kernel time of the cd launch with its right-hand side 11.7 -> 7.9 us, cl 8.9 -> 6.5).  The T
 //   system keeps the 32-row tiles: its deep chains leave no interior in a 16-row tile, and its time is the
 //   per-sweep exchange (0.37 us a sweep, the same with 16 waves x 2 rows: measured, 8.2 -> 8.7 us).
+// SHAPE_OCT: 8 waves x 8 rows (64-row tiles), the T system on large meshes.  The tile of SHAPE_LARGE -- the same
+//   halo overhead per node -- with half the rows per thread: 78 registers instead of 127 (six waves per SIMD
+//   instead of four), eight instead of sixteen per-row lane masks and row offsets in scalar registers, which
+//   SHAPE_LARGE spills into vector lanes (370 of its 2460 instructions move them back and forth), for twice the
+//   seam rows through LDS.  Warm 7-sweep chain at 16384^2, alternated inside one context: 3.42 -> 2.98 ms; 16
+//   waves x 4 rows were measured too: 3.88.
 // All shapes perform the same arithmetic on every node they write: results do not depend on the shape.
-enum : int { SHAPE_LARGE = 0, SHAPE_SMALL = 1, SHAPE_MID = 2, SHAPE_TINY = 3 };
+enum : int { SHAPE_LARGE = 0, SHAPE_SMALL = 1, SHAPE_MID = 2, SHAPE_TINY = 3, SHAPE_OCT = 4 };
 
 template <int VAR, int SHAPE>
 struct StripShape {
-    static constexpr int R = (SHAPE == SHAPE_LARGE) ? 16 : (SHAPE == SHAPE_TINY) ? 2 : 4;  // rows per thread
+    static constexpr int R = (SHAPE == SHAPE_LARGE) ? 16 : (SHAPE == SHAPE_OCT) ? 8 : (SHAPE == SHAPE_TINY) ? 2 : 4;  // rows per thread
     static constexpr int W = (SHAPE == SHAPE_LARGE) ? 4 : (SHAPE == SHAPE_MID) ? 12 : 8;  // waves per workgroup
     static constexpr int TR = R * W;                            // tile height (nodes), halo included
     // waves per SIMD the register budget is set for
@@ -66,7 +72,7 @@ struct StripShape {
     static constexpr int OCC_FUSED = (SHAPE == SHAPE_MID) ? 3 : (VAR == VAR_CD) ? 2 : 3;
 };
 __host__ __device__ inline int strip_tile_rows(int shape) {
-    return shape == SHAPE_TINY ? 16 : shape == SHAPE_SMALL ? 32 : shape == SHAPE_MID ? 48 : 64;
+    return shape == SHAPE_TINY ? 16 : shape == SHAPE_SMALL ? 32 : shape == SHAPE_MID ? 48 : 64;  // (SHAPE_LARGE, SHAPE_OCT)
 }
 
 // column halo of a launch of depth H: H rounded up to even, so that the row segments a wave reads and

@@ -41,6 +41,7 @@ def test_mms_exact_and_forcing(tag):
 # arrays made by a launch of their own instead of by the predictor launch
 SOLVERS = {"strip": {"strip_solve": 1}, "strip_large": {"strip_shape": 0}, "strip_small": {"strip_shape": 1},
            "strip_small_h3": {"strip_shape": 1, "strip_hmax": 3}, "strip_mid": {"strip_shape": 2}, "strip_two_rows": {"strip_shape": 3},
+           "strip_eight_rows": {"strip_shape": 4}, "strip_eight_rows_h3": {"strip_shape": 4, "strip_hmax": 3},
            "strip_two_rows_h3": {"strip_shape": 3, "strip_hmax": 3}, "strip_h1": {"strip_solve": 1, "strip_hmax": 1},
            "strip_h2": {"strip_solve": 1, "strip_hmax": 2}, "strip_h3": {"strip_solve": 1, "strip_hmax": 3},
            "sweeps": {"strip_solve": 0}, "forcing_in_kernels": {"cache_forcing": 0},

@@ -135,11 +135,13 @@ def test_odd_nonuniform_mesh_variants_agree():
     for a in ref["state"]:
         assert np.isfinite(a).all()
     scale = [max(np.max(np.abs(a)), 1.0) for a in ref["state"]]
-    exact = ("shape 0", "shape 1", "shape 2", "shape 1 depth 3", "shape 2 depth 2", "shape 3", "shape 3 depth 2")
+    exact = ("shape 0", "shape 1", "shape 2", "shape 1 depth 3", "shape 2 depth 2", "shape 3", "shape 3 depth 2", "shape 4",
+             "shape 4 depth 3")
     for name, opts in (("shape 0", {"strip_shape": 0}), ("shape 1", {"strip_shape": 1}), ("shape 2", {"strip_shape": 2}),
                        ("shape 1 depth 3", {"strip_shape": 1, "strip_hmax": 3}),
                        ("shape 2 depth 2", {"strip_shape": 2, "strip_hmax": 2}),
                        ("shape 3", {"strip_shape": 3}), ("shape 3 depth 2", {"strip_shape": 3, "strip_hmax": 2}),
+                       ("shape 4", {"strip_shape": 4}), ("shape 4 depth 3", {"strip_shape": 4, "strip_hmax": 3}),
                        ("sweeps", {"strip_solve": 0}), ("forcing in kernels", {"cache_forcing": 0}),
                        ("forcing launch", {"fuse_forcing": 0})):
         r = _run(N, 3, opts, True, M=M, stretch=1.15)
@@ -175,7 +177,7 @@ def test_tile_shapes_and_depths_bit_identical(N, M, react):
 
     ref = run({"strip_solve": 0})
     first = None
-    for shape in (0, 1, 2, 3):  # (3: two rows per thread, 16-row tiles, cl and cd)
+    for shape in (0, 1, 2, 3, 4):  # (3: two rows per thread, 16-row tiles, cl and cd; 4: eight rows per thread, 64-row tiles, T)
         for hmax in (1, 3, 10):
             out = run({"strip_shape": shape, "strip_hmax": hmax})
             first = out if first is None else first

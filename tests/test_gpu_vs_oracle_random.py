@@ -16,7 +16,7 @@ def hip_library():
     yield
 
 
-VARIANTS = {"default": None, "large_tiles": {"strip_shape": 0}, "mid_tiles_h3": {"strip_shape": 2, "strip_hmax": 3},
+VARIANTS = {"default": None, "large_tiles": {"strip_shape": 0}, "eight_row_strips": {"strip_shape": 4}, "mid_tiles_h3": {"strip_shape": 2, "strip_hmax": 3},
             "sweeps": {"strip_solve": 0}}
 
 
