@@ -53,11 +53,12 @@ constexpr int kSTile = 64;  // tile width (nodes = lanes), halo included
 //   system keeps the 32-row tiles: its deep chains leave no interior in a 16-row tile, and its time is the
 //   per-sweep exchange (0.37 us a sweep, the same with 16 waves x 2 rows: measured, 8.2 -> 8.7 us).
 // SHAPE_OCT: 8 waves x 8 rows (64-row tiles), the T system on large meshes.  The tile of SHAPE_LARGE -- the same
-//   halo overhead per node -- with half the rows per thread: 78 registers instead of 127 (six waves per SIMD
-//   instead of four), eight instead of sixteen per-row lane masks and row offsets in scalar registers, which
-//   SHAPE_LARGE spills into vector lanes (370 of its 2460 instructions move them back and forth), for twice the
-//   seam rows through LDS.  Warm 7-sweep chain at 16384^2, alternated inside one context: 3.42 -> 2.98 ms; 16
-//   waves x 4 rows were measured too: 3.88.
+//   halo overhead per node -- with half the rows per thread: 78 registers instead of 127, so six waves per SIMD
+//   instead of four, and eight instead of sixteen per-row lane masks and row offsets in scalar registers (56
+//   instead of 373 instructions that move scalars in and out of vector lanes), for twice the seam rows through
+//   LDS.  The instructions executed per node are the same (389); what changes is how many waves are there to
+//   issue them.  Warm 7-sweep chain at 16384^2, alternated inside one context: 3.42 -> 2.98 ms; 16 waves x 4
+//   rows were measured too: 3.88.
 // All shapes perform the same arithmetic on every node they write: results do not depend on the shape.
 enum : int { SHAPE_LARGE = 0, SHAPE_SMALL = 1, SHAPE_MID = 2, SHAPE_TINY = 3, SHAPE_OCT = 4 };
 
