@@ -155,7 +155,9 @@ int32_t tedd_pitch(const tedd_ctx* ctx);      /* device row pitch in doubles (>=
  * buffer sizes apart while that fits into half of the free device memory (the gaps stay unused), packed back to
  * back otherwise: launches that stream many arrays at once run up to 8 % slower with the buffers in consecutive
  * separate allocations.  TEDD_FIELD_GAP_MB in the environment sets the gap (MiB; 0 packed, -1 separate
- * allocations).  The string names the layout chosen, or why the buffers were allocated one by one; it belongs to the
+ * allocations).  An arena of a quarter of the device memory or more is streamed through when it is taken and
+ * taken again if it lies in the slower of the two kinds of memory such an allocation is given in turn (the
+ * measured rates are part of the string; TEDD_FIELD_PROBE=0 keeps the first allocation).  The string names the layout chosen, or why the buffers were allocated one by one; it belongs to the
  * context and is valid until tedd_destroy. */
 const char* tedd_placement(const tedd_ctx* ctx);
 

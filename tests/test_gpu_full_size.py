@@ -127,6 +127,31 @@ def test_bench_mesh_16384():
     np.testing.assert_array_equal(r["norms"], ref["norms"])
 
 
+def test_consecutive_contexts_of_the_bench_mesh_stream_alike():
+    """The arena of a 16384^2 context is given one of two kinds of physical memory in turn when contexts are made
+    one after the other (13 reads + 7 writes stream at 6.5 or at 5.9 TB/s; the predictor takes 7.5 or 8.2 ms); the
+    library streams through the arena when it takes it and takes turns until it holds the faster kind.  Three
+    contexts in a row: the placement note says what was measured, and the predictor launches agree to 3 %."""
+    from tedd import _ffi
+    N = 16384
+    x = np.linspace(0, 1, N + 1)
+    dt = (1.0 / N) ** 1.5
+    times = []
+    for _ in range(3):
+        ctx = _ffi.Context(x, x, NB_A, model_kind=2, reaction_kind=_ffi.REACT_REGHCSTRIPLE, eta=50.0, mms_case=_ffi.MMS_EXPSIN)
+        assert "one arena of 32 buffers" in ctx.placement and "streamed at" in ctx.placement, ctx.placement
+        ctx.set_state_exact(0.0)
+        ctx.advance(0.0, dt, 3, want_errors=False)
+        ctx.profile_enable(True)
+        for k in range(3):
+            ctx.step_pc((3 + k) * dt, dt)
+        ctx.sync()
+        prof = ctx.profile_get()
+        ctx.close()
+        times.append(prof["predict"]["total_ms"] / prof["predict"]["launches"])
+    assert max(times) <= 1.03 * min(times), times
+
+
 def test_odd_nonuniform_mesh_variants_agree():
     """A 1001 x 778-node non-uniform mesh (no dimension a multiple of the tile sizes): every tile shape and
     chain depth of the solve, the per-sweep solver and both forcing modes give the same state."""

@@ -115,6 +115,22 @@ int main(int argc, char** argv) {
     const size_t S2M = (bytes + 2 * MB - 1) / (2 * MB) * (2 * MB);
     const size_t arena_bytes = 32 * 2 * S2M;
     char* arena;
+    if (argc > 2 && argv[2][0] == 'r') {
+        // the same arena allocated, streamed and freed again and again: do two physical regions take turns, and does a
+        // plain stream tell them apart?  (the library's contexts alternate between two states when made one after the other)
+        for (int rep = 0; rep < 8; ++rep) {
+            CK(hipMalloc(&arena, arena_bytes));
+            CK(hipMemset(arena, 0, arena_bytes));
+            const double* b = (const double*)arena;
+            const size_t st = 2 * S2M / 8;
+            printf("allocation %d at %p: 13 R + 7 W %5.0f GB/s, with 564 instructions a row %5.0f, 6 R + 1 W %5.0f, 4 R + 1 W %5.0f\n", rep,
+                   (void*)arena, run<13, 7, 1, true>(b, st, ld, n, 32, 2, 0, 4), run<13, 7, 1, true>(b, st, ld, n, 32, 2, 564, 4),
+                   run<6, 1, 1, true>(b, st, ld, n, 32, 4, 0, 4), run<4, 1, 1, true>(b, st, ld, n, 32, 4, 0, 4));
+            fflush(stdout);
+            CK(hipFree(arena));
+        }
+        return 0;
+    }
     CK(hipMalloc(&arena, arena_bytes));
     CK(hipMemset(arena, 0, arena_bytes));
     const double* base = (const double*)arena;
